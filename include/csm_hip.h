@@ -1,0 +1,264 @@
+/* csm_hip.h -- C ABI of libcsm_hip.so, the MI355X (gfx950) correlative
+ * scan-matching backend.
+ *
+ * Drop-in boundary for the correlative / branch-and-bound matching path of
+ * sterngerlach/my-lidar-graph-slam-v2. Each entry point cites the reference
+ * interface it replaces (paths relative to the reference tree,
+ * inc/ = include/my_lidar_graph_slam/, src/ = src/my_lidar_graph_slam/).
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a host pointer unless its name ends
+ *    in _dev; inputs are borrowed for the duration of the call.
+ *  - every function returns 0 on success or a negative errno-style code;
+ *    csm_last_error() gives the text. Nothing throws across the boundary.
+ *  - no global state: one csm_ctx per matcher / detector object, single caller
+ *    per ctx (the reference never shares a matcher between its two threads,
+ *    src/slam_module_factory.cpp:102-104 vs src/loop_detector_factory.cpp:180-183).
+ *  - occupancy values are the reference's raw uint16 cells: 0 = unknown,
+ *    1..65535 <-> P in [0.001, 0.999] (inc/grid_map_new/grid_binary_bayes.hpp:163-176).
+ *  - there is no CPU fallback: without a GPU every compute entry point fails
+ *    with CSM_ENODEV.
+ */
+#ifndef CSM_HIP_H
+#define CSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSM_OK       0
+#define CSM_ENOENT  (-2)   /* unknown map id / level */
+#define CSM_EIO     (-5)   /* HIP runtime error */
+#define CSM_ENOMEM  (-12)
+#define CSM_ENODEV  (-19)  /* no usable GPU */
+#define CSM_EINVAL  (-22)
+
+/* csm_result.flags */
+#define CSM_FLAG_EDGE_BAND   1u  /* a coarse read fell in the negative edge band
+                                    (SURVEY 8(a) A8): resolved by the literal
+                                    sequential device path */
+#define CSM_FLAG_KEY_TIE     2u  /* several candidates shared the best integer
+                                    key: resolved by the f64 replay */
+#define CSM_FLAG_F64_TIE     4u  /* several candidates share the best f64 score
+                                    bit for bit (branch-and-bound: the reference's
+                                    choice then depends on heap order) */
+#define CSM_FLAG_LITERAL     8u  /* result produced by the literal path */
+#define CSM_FLAG_PROJ_DELTA 16u  /* branch-and-bound: some per-node projection
+                                    differed from base+offset and was corrected */
+
+typedef struct csm_ctx csm_ctx;
+
+typedef struct {
+    int32_t device_id;      /* HIP device ordinal */
+    int32_t reserved[7];
+} csm_config;
+
+/* Geometry of a grid map: inc/grid_map_new/grid_map_geometry.hpp:228-240 */
+typedef struct {
+    double  resolution;     /* metres per cell */
+    double  offset_x;       /* mPosOffset.mX */
+    double  offset_y;       /* mPosOffset.mY */
+} csm_geometry;
+
+/* One scan: inc/sensor/sensor_data.hpp (ScanData<double>: Angles(), Ranges(),
+ * RelativeSensorPose()) */
+typedef struct {
+    const double* angles;
+    const double* ranges;
+    int32_t       n_points;
+    int32_t       reserved;
+    double        relative_sensor_pose[3];
+} csm_scan;
+
+/* ScanMatcherCorrelative constructor arguments
+ * (inc/mapping/scan_matcher_correlative.hpp:58-66,
+ *  src/scan_matcher_factory.cpp:173-177) plus the two thresholds of the
+ * 6-argument OptimizePose overload (scan_matcher_correlative.hpp:75-81) */
+typedef struct {
+    double  range_x, range_y, range_theta;
+    int32_t low_resolution;
+    int32_t reserved;
+    double  score_threshold;
+    double  known_rate_threshold;
+} csm_correlative_params;
+
+/* ScanMatcherBranchBound constructor arguments
+ * (inc/mapping/scan_matcher_branch_bound.hpp:109-118,
+ *  src/scan_matcher_factory.cpp:22-26) plus thresholds */
+typedef struct {
+    double  range_x, range_y, range_theta;
+    int32_t node_height_max;
+    int32_t reserved;
+    double  score_threshold;
+    double  known_rate_threshold;
+} csm_bnb_params;
+
+/* Raw search result (the device-side record; 48 bytes, also the unit of the
+ * multi-GPU all-gather). Offsets are in search steps relative to the sensor
+ * pose, exactly the reference's bestWinX/Y/Theta
+ * (src/mapping/scan_matcher_correlative.cpp:149-152, 203-206). */
+typedef struct {
+    int32_t  found;
+    int32_t  best_x, best_y, best_theta;
+    uint64_t key;          /* 32268*K + 499*S: exact integer order of the score */
+    uint32_t sum_values;   /* S: sum of raw cell values over known hit cells */
+    uint32_t known;        /* K: number of known hit cells */
+    uint32_t tie_count;    /* candidates sharing the best key */
+    uint32_t flags;
+    double   score;        /* normalized score of the winner, f64, beam order:
+                              the reference's scoreMax */
+} csm_result;
+
+/* Everything ScanMatchingSummary needs from the search
+ * (inc/mapping/scan_matcher.hpp:53-82) plus the metric inputs of
+ * src/mapping/scan_matcher_correlative.cpp:222-236. Cost and covariance
+ * (lines 209-219) stay with the caller's CostFunction. */
+typedef struct {
+    int32_t    pose_found;
+    int32_t    win_x, win_y, win_theta;
+    double     step_x, step_y, step_theta;
+    double     sensor_pose[3];       /* Compound(initial, relative sensor pose) */
+    double     best_sensor_pose[3];
+    double     estimated_pose[3];    /* MoveBackward(best, relative sensor pose) */
+    double     input_setup_us;       /* upload / pyramid time */
+    double     optimization_us;
+    int64_t    candidates;           /* fine candidate poses fully scored */
+    csm_result raw;
+} csm_summary;
+
+/* One loop-detection query (inc/mapping/loop_detector.hpp:27-55 flattened:
+ * the reference local map is named by map_id, the query scan node by scan +
+ * map-local initial pose, loop_detector_branch_bound.cpp:97-104). */
+typedef struct {
+    uint64_t     map_id;
+    csm_geometry geometry;
+    csm_scan     scan;
+    double       initial_pose[3];
+} csm_loop_query;
+
+/* ---- life cycle (replaces the matcher constructors; device-init failure is
+ * reported like LoadBitstream does, src/slam_launcher.cpp:83-107) ---- */
+int  csm_create(const csm_config* cfg, csm_ctx** out);
+int  csm_destroy(csm_ctx* ctx);
+const char* csm_last_error(const csm_ctx* ctx);
+/* Use an existing HIP stream (hipStream_t) for all work of this ctx; NULL =
+ * the ctx's own stream. */
+int  csm_set_stream(csm_ctx* ctx, void* hip_stream);
+int  csm_synchronize(csm_ctx* ctx);
+
+/* ---- grid maps. Replaces GridMap::CopyValues + the per-LocalMapId cache
+ * (src/grid_map_new/grid_map.cpp:439-457;
+ *  inc/mapping/loop_detector_branch_bound.hpp:50-69, 98;
+ *  src/mapping/scan_matcher_correlative_fpga.cpp:261-262) ---- */
+int  csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense,
+                     int32_t rows, int32_t cols);
+int  csm_has_grid(csm_ctx* ctx, uint64_t map_id);   /* 1 / 0 */
+int  csm_release_grid(csm_ctx* ctx, uint64_t map_id);
+
+/* PrecomputeGridMap(s) on device (src/mapping/grid_map_builder.cpp:987-1065):
+ * level i of map_id becomes the forward box-max with window win_sizes[i]
+ * (win_sizes[0] is normally 1). Level 0 always aliases the uploaded grid when
+ * win_sizes[0] == 1. */
+int  csm_build_pyramid(csm_ctx* ctx, uint64_t map_id, const int32_t* win_sizes,
+                       int32_t n_levels);
+int  csm_download_level(csm_ctx* ctx, uint64_t map_id, int32_t level,
+                        uint16_t* out /* rows*cols */);
+
+/* ---- host-side set-up pieces (pure CPU, exported so the adapter and the
+ * tests share one implementation) ---- */
+/* ComputeSearchStep: src/mapping/scan_matcher_correlative.cpp:255-274 */
+int  csm_host_search_step(double resolution, const double* ranges, int32_t n,
+                          double* step_x, double* step_y, double* step_theta);
+/* Window half-widths: scan_matcher_correlative.cpp:141-146 */
+int  csm_host_window(double range, double step);
+/* Smallest known count K with double(K)/double(n) > known_rate_threshold
+ * (the test of scan_matcher_correlative.cpp:181-182 as an integer bound) */
+int  csm_host_min_known(int32_t n_points, double known_rate_threshold);
+/* Compound / MoveBackward: inc/pose.hpp:154-166, 215-227 */
+void csm_host_compound(const double start[3], const double diff[3], double out[3]);
+void csm_host_inverse_compound(const double start[3], const double end[3], double out[3]);
+void csm_host_move_backward(const double end[3], const double diff[3], double out[3]);
+/* ComputeScanIndices for n_theta slices t = -win_theta..win_theta
+ * (scan_matcher_correlative.cpp:161-168, 277-297): out arrays are
+ * [n_theta][n_points]; also returns r*cos / r*sin per slice if non-NULL
+ * (needed by the branch-and-bound projection). */
+int  csm_host_project(const csm_geometry* geom, const double sensor_pose[3],
+                      double step_theta, int32_t win_theta,
+                      const double* angles, const double* ranges, int32_t n,
+                      int32_t* hit_col, int32_t* hit_row,
+                      double* r_cos, double* r_sin);
+/* value -> probability table, 65536 doubles
+ * (inc/grid_map_new/grid_values.hpp:26-35) */
+void csm_host_probability_lut(double* lut);
+
+/* ---- the hot path ---- */
+
+/* Pre-projected search window, CSM flavour: replaces the theta/x/y sweep of
+ * src/mapping/scan_matcher_correlative.cpp:161-197 + 339-368 for one query. */
+typedef struct {
+    int32_t n_theta;          /* 2*win_theta+1 */
+    int32_t n_points;
+    int32_t win_x, win_y;
+    int32_t low_resolution;   /* L; level `coarse_level` must be box-max(L) */
+    int32_t coarse_level;
+    int32_t min_known;        /* csm_host_min_known() */
+    int32_t reserved;
+    double  score_threshold;
+} csm_window;
+
+/* hit_col / hit_row: [n_theta][n_points] int32, host memory. */
+int  csm_score_window(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
+                      const int32_t* hit_col, const int32_t* hit_row,
+                      csm_result* out);
+/* Same with device-resident inputs and output (asynchronous on the ctx
+ * stream; no host synchronisation unless a tie / edge-band path is needed,
+ * in which case out_dev->flags tells and csm_resolve_window_dev() finishes). */
+int  csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
+                          const int32_t* hit_col_dev, const int32_t* hit_row_dev,
+                          csm_result* out_dev);
+/* Optional dump of every candidate's integer sums for parity tests:
+ * S [n_theta][nx][ny] uint32 and K [..] uint16 (nx = ceil((2*win_x+1)/L)*L),
+ * coarse K [n_theta][nx/L][ny/L]. Host pointers, any may be NULL. */
+int  csm_score_window_dump(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
+                           const int32_t* hit_col, const int32_t* hit_row,
+                           csm_result* out, uint32_t* dump_s, uint16_t* dump_k,
+                           uint16_t* dump_coarse_k);
+
+/* ScanMatcherCorrelative::OptimizePose, both overloads
+ * (src/mapping/scan_matcher_correlative.cpp:92-115, 118-244): uploads nothing;
+ * the grid must be resident under map_id; builds box-max(L) if missing. */
+int  csm_correlative_match(csm_ctx* ctx, uint64_t map_id,
+                           const csm_geometry* geom, const csm_scan* scan,
+                           const double initial_pose[3],
+                           const csm_correlative_params* params,
+                           csm_summary* out);
+
+/* LoopDetectorBranchBound::Detect's search part for a batch of queries
+ * (src/mapping/loop_detector_branch_bound.cpp:59-156 lines 68-108;
+ *  ScanMatcherBranchBound::OptimizePose, scan_matcher_branch_bound.cpp:111-278).
+ * Every map_id must be resident; pyramids are built and cached on first use.
+ * out[i] corresponds to queries[i] (pose_found = 0 when the reference would
+ * `continue`). */
+int  csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
+                         int32_t n_queries, const csm_bnb_params* params,
+                         csm_summary* out);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* When enabled, every launch of the dominant scoring kernel is bracketed by
+ * HIP events on the ctx stream. */
+int  csm_enable_kernel_timing(csm_ctx* ctx, int32_t enable);
+/* Drains recorded events; returns total ms and launch count since the last
+ * reset for kernel "score_fine" | "score_coarse" | "bin" | "finalize" | "boxmax". */
+int  csm_kernel_time(csm_ctx* ctx, const char* name, double* total_ms,
+                     int64_t* launches);
+int  csm_reset_kernel_timing(csm_ctx* ctx);
+
+/* Library / build identification */
+const char* csm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSM_HIP_H */

@@ -1,0 +1,150 @@
+"""ctypes binding of libcsm_hip.so (the C ABI declared in include/csm_hip.h).
+
+The library is built in-tree (my-lidar-graph-slam-v2_amd/csrc/libcsm_hip.so) by
+__graft_entry__.build(). There is no fallback: if the shared object is missing
+the import fails, and without a GPU every compute entry point returns
+CSM_ENODEV.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcsm_hip.so")
+
+CSM_OK = 0
+CSM_ENOENT = -2
+CSM_EIO = -5
+CSM_ENOMEM = -12
+CSM_ENODEV = -19
+CSM_EINVAL = -22
+
+FLAG_EDGE_BAND = 1
+FLAG_KEY_TIE = 2
+FLAG_F64_TIE = 4
+FLAG_LITERAL = 8
+FLAG_PROJ_DELTA = 16
+
+
+class Config(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("offset_x", C.c_double),
+                ("offset_y", C.c_double)]
+
+
+class Scan(C.Structure):
+    _fields_ = [("angles", C.POINTER(C.c_double)),
+                ("ranges", C.POINTER(C.c_double)),
+                ("n_points", C.c_int32), ("reserved", C.c_int32),
+                ("relative_sensor_pose", C.c_double * 3)]
+
+
+class CorrelativeParams(C.Structure):
+    _fields_ = [("range_x", C.c_double), ("range_y", C.c_double),
+                ("range_theta", C.c_double), ("low_resolution", C.c_int32),
+                ("reserved", C.c_int32), ("score_threshold", C.c_double),
+                ("known_rate_threshold", C.c_double)]
+
+
+class BnbParams(C.Structure):
+    _fields_ = [("range_x", C.c_double), ("range_y", C.c_double),
+                ("range_theta", C.c_double), ("node_height_max", C.c_int32),
+                ("reserved", C.c_int32), ("score_threshold", C.c_double),
+                ("known_rate_threshold", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("found", C.c_int32), ("best_x", C.c_int32),
+                ("best_y", C.c_int32), ("best_theta", C.c_int32),
+                ("key", C.c_uint64), ("sum_values", C.c_uint32),
+                ("known", C.c_uint32), ("tie_count", C.c_uint32),
+                ("flags", C.c_uint32), ("score", C.c_double)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("pose_found", C.c_int32), ("win_x", C.c_int32),
+                ("win_y", C.c_int32), ("win_theta", C.c_int32),
+                ("step_x", C.c_double), ("step_y", C.c_double),
+                ("step_theta", C.c_double), ("sensor_pose", C.c_double * 3),
+                ("best_sensor_pose", C.c_double * 3),
+                ("estimated_pose", C.c_double * 3),
+                ("input_setup_us", C.c_double), ("optimization_us", C.c_double),
+                ("candidates", C.c_int64), ("raw", Result)]
+
+
+class LoopQuery(C.Structure):
+    _fields_ = [("map_id", C.c_uint64), ("geometry", Geometry), ("scan", Scan),
+                ("initial_pose", C.c_double * 3)]
+
+
+class Window(C.Structure):
+    _fields_ = [("n_theta", C.c_int32), ("n_points", C.c_int32),
+                ("win_x", C.c_int32), ("win_y", C.c_int32),
+                ("low_resolution", C.c_int32), ("coarse_level", C.c_int32),
+                ("min_known", C.c_int32), ("reserved", C.c_int32),
+                ("score_threshold", C.c_double)]
+
+
+# name -> (restype, argtypes); mirrors include/csm_hip.h one to one
+_P = C.POINTER
+_ctx = C.c_void_p
+SIGNATURES = {
+    "csm_create": (C.c_int, [_P(Config), _P(_ctx)]),
+    "csm_destroy": (C.c_int, [_ctx]),
+    "csm_last_error": (C.c_char_p, [_ctx]),
+    "csm_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "csm_synchronize": (C.c_int, [_ctx]),
+    "csm_upload_grid": (C.c_int, [_ctx, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32]),
+    "csm_has_grid": (C.c_int, [_ctx, C.c_uint64]),
+    "csm_release_grid": (C.c_int, [_ctx, C.c_uint64]),
+    "csm_build_pyramid": (C.c_int, [_ctx, C.c_uint64, _P(C.c_int32), C.c_int32]),
+    "csm_download_level": (C.c_int, [_ctx, C.c_uint64, C.c_int32, C.c_void_p]),
+    "csm_host_search_step": (C.c_int, [C.c_double, C.c_void_p, C.c_int32,
+                                       _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "csm_host_window": (C.c_int, [C.c_double, C.c_double]),
+    "csm_host_min_known": (C.c_int, [C.c_int32, C.c_double]),
+    "csm_host_compound": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "csm_host_inverse_compound": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "csm_host_move_backward": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "csm_host_project": (C.c_int, [_P(Geometry), C.c_void_p, C.c_double, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "csm_host_probability_lut": (None, [C.c_void_p]),
+    "csm_score_window": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
+                                   C.c_void_p, _P(Result)]),
+    "csm_score_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "csm_score_window_dump": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
+                                        C.c_void_p, _P(Result), C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "csm_correlative_match": (C.c_int, [_ctx, C.c_uint64, _P(Geometry), _P(Scan),
+                                        C.c_void_p, _P(CorrelativeParams), _P(Summary)]),
+    "csm_bnb_match_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32,
+                                      _P(BnbParams), _P(Summary)]),
+    "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),
+    "csm_kernel_time": (C.c_int, [_ctx, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
+    "csm_reset_kernel_timing": (C.c_int, [_ctx]),
+    "csm_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcsm_hip.so and declare every entry point. Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libcsm_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(expected at %s)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,285 @@
+"""Thin Python host layer over the C ABI (include/csm_hip.h).
+
+Mirrors the reference's matcher interface for the hot path:
+  ScanMatcherCorrelativeHIP.optimize_pose(...)   <- ScanMatcherCorrelative::OptimizePose
+  (src/my_lidar_graph_slam/mapping/scan_matcher_correlative.cpp:92-244)
+  LoopDetectorBranchBoundHIP.detect(...)         <- LoopDetectorBranchBound::Detect
+  (src/my_lidar_graph_slam/mapping/loop_detector_branch_bound.cpp:59-156)
+All arithmetic happens in libcsm_hip.so; this file only marshals numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class CsmError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("csm_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def result_to_dict(r):
+    return dict(found=int(r.found), best_x=int(r.best_x), best_y=int(r.best_y),
+                best_theta=int(r.best_theta), key=int(r.key),
+                sum_values=int(r.sum_values), known=int(r.known),
+                tie_count=int(r.tie_count), flags=int(r.flags), score=float(r.score))
+
+
+def summary_to_dict(s):
+    return dict(pose_found=int(s.pose_found), win_x=s.win_x, win_y=s.win_y,
+                win_theta=s.win_theta, step_x=s.step_x, step_y=s.step_y,
+                step_theta=s.step_theta, sensor_pose=list(s.sensor_pose),
+                best_sensor_pose=list(s.best_sensor_pose),
+                estimated_pose=list(s.estimated_pose),
+                input_setup_us=s.input_setup_us, optimization_us=s.optimization_us,
+                candidates=int(s.candidates), raw=result_to_dict(s.raw))
+
+
+# ---- host-only helpers (no GPU needed) ----
+
+def host_search_step(resolution, ranges):
+    lib = L.load()
+    r = _f64(ranges)
+    sx, sy, st = C.c_double(), C.c_double(), C.c_double()
+    rc = lib.csm_host_search_step(resolution, _ptr(r), r.size, C.byref(sx), C.byref(sy), C.byref(st))
+    if rc:
+        raise CsmError(rc, "csm_host_search_step")
+    return sx.value, sy.value, st.value
+
+
+def host_window(rng, step):
+    return L.load().csm_host_window(rng, step)
+
+
+def host_min_known(n, thr):
+    return L.load().csm_host_min_known(n, thr)
+
+
+def host_compound(a, b):
+    out = np.zeros(3)
+    L.load().csm_host_compound(_ptr(_f64(a)), _ptr(_f64(b)), _ptr(out))
+    return out
+
+
+def host_inverse_compound(a, b):
+    out = np.zeros(3)
+    L.load().csm_host_inverse_compound(_ptr(_f64(a)), _ptr(_f64(b)), _ptr(out))
+    return out
+
+
+def host_move_backward(a, b):
+    out = np.zeros(3)
+    L.load().csm_host_move_backward(_ptr(_f64(a)), _ptr(_f64(b)), _ptr(out))
+    return out
+
+
+def host_project(geom, sensor_pose, step_theta, win_theta, angles, ranges, want_products=False):
+    lib = L.load()
+    a, r = _f64(angles), _f64(ranges)
+    n, nt = a.size, 2 * win_theta + 1
+    col = np.zeros((nt, n), np.int32)
+    row = np.zeros((nt, n), np.int32)
+    rc_ = np.zeros((nt, n)) if want_products else None
+    rs_ = np.zeros((nt, n)) if want_products else None
+    g = L.Geometry(*geom)
+    sp = _f64(sensor_pose)
+    rc = lib.csm_host_project(C.byref(g), _ptr(sp), step_theta, win_theta, _ptr(a), _ptr(r), n,
+                              _ptr(col), _ptr(row),
+                              _ptr(rc_) if want_products else None,
+                              _ptr(rs_) if want_products else None)
+    if rc:
+        raise CsmError(rc, "csm_host_project")
+    return (col, row, rc_, rs_) if want_products else (col, row)
+
+
+def host_probability_lut():
+    lut = np.zeros(65536)
+    L.load().csm_host_probability_lut(_ptr(lut))
+    return lut
+
+
+class Context:
+    """One csm_ctx: owns the device grids, workspaces and a stream."""
+
+    def __init__(self, device_id=0):
+        self.lib = L.load()
+        self._ctx = C.c_void_p()
+        cfg = L.Config()
+        cfg.device_id = device_id
+        rc = self.lib.csm_create(C.byref(cfg), C.byref(self._ctx))
+        if rc:
+            self._ctx = C.c_void_p()
+            raise CsmError(rc, "csm_create failed (no GPU?)")
+        self.shapes = {}
+
+    def close(self):
+        if self._ctx:
+            self.lib.csm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise CsmError(rc, self.lib.csm_last_error(self._ctx).decode())
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.csm_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self.lib.csm_synchronize(self._ctx))
+
+    def upload_grid(self, map_id, grid):
+        g = np.ascontiguousarray(grid, dtype=np.uint16)
+        self._check(self.lib.csm_upload_grid(self._ctx, map_id, _ptr(g), g.shape[0], g.shape[1]))
+        self.shapes[map_id] = g.shape
+
+    def has_grid(self, map_id):
+        return bool(self.lib.csm_has_grid(self._ctx, map_id))
+
+    def release_grid(self, map_id):
+        self._check(self.lib.csm_release_grid(self._ctx, map_id))
+        self.shapes.pop(map_id, None)
+
+    def build_pyramid(self, map_id, win_sizes):
+        w = np.ascontiguousarray(win_sizes, dtype=np.int32)
+        self._check(self.lib.csm_build_pyramid(
+            self._ctx, map_id, w.ctypes.data_as(C.POINTER(C.c_int32)), w.size))
+
+    def download_level(self, map_id, level):
+        out = np.zeros(self.shapes[map_id], np.uint16)
+        self._check(self.lib.csm_download_level(self._ctx, map_id, level, _ptr(out)))
+        return out
+
+    @staticmethod
+    def make_window(n_theta, n_points, win_x, win_y, low_resolution, coarse_level,
+                    min_known, score_threshold):
+        w = L.Window()
+        w.n_theta, w.n_points = n_theta, n_points
+        w.win_x, w.win_y = win_x, win_y
+        w.low_resolution, w.coarse_level = low_resolution, coarse_level
+        w.min_known, w.score_threshold = min_known, score_threshold
+        return w
+
+    def score_window(self, map_id, window, hit_col, hit_row, dump=False):
+        col = np.ascontiguousarray(hit_col, dtype=np.int32)
+        row = np.ascontiguousarray(hit_row, dtype=np.int32)
+        res = L.Result()
+        if not dump:
+            self._check(self.lib.csm_score_window(self._ctx, map_id, C.byref(window),
+                                                  _ptr(col), _ptr(row), C.byref(res)))
+            return result_to_dict(res)
+        Lr = window.low_resolution
+        nxc = -(-(2 * window.win_x + 1) // Lr)
+        nyc = -(-(2 * window.win_y + 1) // Lr)
+        s = np.zeros((window.n_theta, nxc * Lr, nyc * Lr), np.uint32)
+        k = np.zeros((window.n_theta, nxc * Lr, nyc * Lr), np.uint16)
+        ck = np.zeros((window.n_theta, nxc, nyc), np.uint16)
+        self._check(self.lib.csm_score_window_dump(self._ctx, map_id, C.byref(window),
+                                                   _ptr(col), _ptr(row), C.byref(res),
+                                                   _ptr(s), _ptr(k), _ptr(ck)))
+        return result_to_dict(res), s, k, ck
+
+    def score_window_dev(self, map_id, window, col_ptr, row_ptr, out_ptr):
+        self._check(self.lib.csm_score_window_dev(self._ctx, map_id, C.byref(window),
+                                                  C.c_void_p(col_ptr), C.c_void_p(row_ptr),
+                                                  C.c_void_p(out_ptr)))
+
+    def correlative_match(self, map_id, geom, angles, ranges, rel_pose, init_pose,
+                          range_x, range_y, range_theta, low_resolution,
+                          score_threshold=0.0, known_rate_threshold=0.0):
+        a, r = _f64(angles), _f64(ranges)
+        scan = L.Scan()
+        scan.angles = a.ctypes.data_as(C.POINTER(C.c_double))
+        scan.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
+        scan.n_points = a.size
+        scan.relative_sensor_pose[:] = list(rel_pose)
+        g = L.Geometry(*geom)
+        p = L.CorrelativeParams()
+        p.range_x, p.range_y, p.range_theta = range_x, range_y, range_theta
+        p.low_resolution = low_resolution
+        p.score_threshold, p.known_rate_threshold = score_threshold, known_rate_threshold
+        init = _f64(init_pose)
+        out = L.Summary()
+        self._check(self.lib.csm_correlative_match(self._ctx, map_id, C.byref(g), C.byref(scan),
+                                                   _ptr(init), C.byref(p), C.byref(out)))
+        return summary_to_dict(out)
+
+    def bnb_match_batch(self, queries, range_x, range_y, range_theta, node_height_max,
+                        score_threshold, known_rate_threshold):
+        """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose)."""
+        n = len(queries)
+        arr = (L.LoopQuery * n)()
+        keep = []
+        for i, q in enumerate(queries):
+            a, r = _f64(q["angles"]), _f64(q["ranges"])
+            keep.append((a, r))
+            arr[i].map_id = q["map_id"]
+            arr[i].geometry = L.Geometry(*q["geom"])
+            arr[i].scan.angles = a.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].scan.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].scan.n_points = a.size
+            arr[i].scan.relative_sensor_pose[:] = list(q["rel_pose"])
+            arr[i].initial_pose[:] = list(q["init_pose"])
+        p = L.BnbParams()
+        p.range_x, p.range_y, p.range_theta = range_x, range_y, range_theta
+        p.node_height_max = node_height_max
+        p.score_threshold, p.known_rate_threshold = score_threshold, known_rate_threshold
+        out = (L.Summary * n)()
+        self._check(self.lib.csm_bnb_match_batch(self._ctx, arr, n, C.byref(p), out))
+        return [summary_to_dict(o) for o in out]
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self.lib.csm_enable_kernel_timing(self._ctx, 1 if on else 0))
+
+    def reset_kernel_timing(self):
+        self._check(self.lib.csm_reset_kernel_timing(self._ctx))
+
+    def kernel_time(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.csm_kernel_time(self._ctx, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class ScanMatcherCorrelativeHIP:
+    """Drop-in for ScanMatcherCorrelative (constructor arguments as in
+    src/my_lidar_graph_slam/scan_matcher_factory.cpp:173-177)."""
+
+    def __init__(self, name, low_resolution, range_x, range_y, range_theta, ctx=None):
+        self.name = name
+        self.low_resolution = low_resolution
+        self.range_x, self.range_y, self.range_theta = range_x, range_y, range_theta
+        self.ctx = ctx or Context()
+        self._nonce = 1 << 62
+
+    def optimize_pose(self, grid, geom, angles, ranges, rel_pose, init_pose,
+                      map_id=None, score_threshold=0.0, known_rate_threshold=0.0):
+        """grid may be None when map_id is already resident (the per-LocalMapId
+        cache of the loop detectors); a throw-away latest map gets a nonce id,
+        like LocalMapId::Invalid in scan_matcher_correlative_fpga.cpp:177-184."""
+        mid = map_id
+        if mid is None:
+            mid = self._nonce
+        if grid is not None and (map_id is None or not self.ctx.has_grid(mid)):
+            self.ctx.upload_grid(mid, grid)
+        out = self.ctx.correlative_match(mid, geom, angles, ranges, rel_pose, init_pose,
+                                         self.range_x, self.range_y, self.range_theta,
+                                         self.low_resolution, score_threshold,
+                                         known_rate_threshold)
+        if map_id is None:
+            self.ctx.release_grid(mid)
+        return out

@@ -1,0 +1,1004 @@
+/* csm_api.hip -- host side of libcsm_hip.so: the C ABI of include/csm_hip.h on
+ * top of the gfx950 kernels in csm_kernels.hip. One translation unit.
+ *
+ * Host-side expressions that must agree bit for bit with the reference
+ * (search step, window, projection, pose algebra) are restated here from the
+ * cited reference lines and are built with -ffp-contract=off.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "csm_kernels.hip"
+
+using namespace csm;
+
+/* ------------------------------------------------------------------ ctx */
+
+namespace {
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct Level {
+    int       win = 1;
+    uint16_t* cells = nullptr;   /* pitched rows*pitch */
+    bool      owned = false;
+};
+
+struct DeviceGrid {
+    int rows = 0, cols = 0, pitch = 0;
+    std::vector<Level> levels;   /* levels[0] is the uploaded grid */
+};
+
+struct TimedSpan {
+    hipEvent_t a, b;
+};
+
+struct KernelTimer {
+    std::vector<TimedSpan> spans;
+    double  total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+} /* namespace */
+
+struct csm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<uint64_t, DeviceGrid> grids;
+    double* lut_dev = nullptr;
+    /* workspaces */
+    DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
+    bool timing = false;
+    std::map<std::string, KernelTimer> timers;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(csm_ctx* ctx, int code, const char* fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                        \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return fail(ctx, CSM_EIO, "%s failed: %s (%s:%d)", #expr,             \
+                        hipGetErrorString(e_), __FILE__, __LINE__);               \
+    } while (0)
+
+int ensure(csm_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return CSM_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.p)
+        HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess)
+        return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", want);
+    b.cap = want;
+    return CSM_OK;
+}
+
+struct ScopedTimer {
+    csm_ctx* ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char* name;
+    ScopedTimer(csm_ctx* c, const char* n) : ctx(c), name(n)
+    {
+        if (!ctx->timing)
+            return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!ctx->event_pool.empty()) {
+                e = ctx->event_pool.back();
+                ctx->event_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, ctx->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (!a)
+            return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->timers[name].spans.push_back({ a, b });
+    }
+};
+
+/* ---- host restatements (bit-exact pieces) ---- */
+
+/* inc/grid_map_new/grid_values.hpp:26-35 with ValueMin 1, ValueMax 65535,
+ * ProbabilityMin 1e-3, ProbabilityMax 1-1e-3
+ * (inc/grid_map_new/grid_binary_bayes.hpp:163-176). The reference table stops
+ * at 65534 (src/grid_map_new/grid_values.cpp:32-33); 65535 follows the same
+ * formula here. */
+double value_to_probability(unsigned v)
+{
+    const double pmin = 1e-3;
+    const double pmax = 1.0 - 1e-3;
+    if (v == 0)
+        return 0.0;
+    return pmin + (pmax - pmin) * static_cast<double>(static_cast<int>(v) - 1) /
+                      static_cast<double>(65535 - 1);
+}
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+/* Launch geometry of one search window. */
+struct Plan {
+    int n_theta = 0, n = 0;
+    int win_x = 0, win_y = 0, L = 1;
+    int nxc = 0, nyc = 0, nx = 0, ny = 0;
+    int x_lo = 0, y_lo = 0, x_hi = 0, y_hi = 0;
+    int lstride = 64;
+    int cbx = 0, groups = 0, R = 8, ncbx = 0, ncby = 0;
+    int c_cbx = 0, c_groups = 0, c_ncbx = 0, c_ncby = 0;
+    int tiles_x = 0, tiles_y = 0, max_tiles = 0;
+};
+
+const int kRChoices[] = { 4, 5, 6, 7, 8 };
+
+void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* R,
+                 int* ncbx, int* ncby, bool fixed_r1)
+{
+    (void)stride_unused;
+    const int nb = ceil_div(nx, 120);
+    *cbx = ceil_div(nx, nb);
+    *ncbx = ceil_div(nx, *cbx);
+    int g = kBlock / *cbx;
+    if (g < 1)
+        g = 1;
+    if (fixed_r1) {
+        *R = 1;
+        if (g > ny)
+            g = ny;
+        *groups = g;
+        *ncby = ceil_div(ny, g);
+        return;
+    }
+    /* pick R (and trim groups) minimising padded candidate rows */
+    long best_cost = -1;
+    for (int r : kRChoices) {
+        int gg = std::min(g, ceil_div(ny, r));
+        const int nby = ceil_div(ny, gg * r);
+        /* cost ~ lane-rows issued (idle lanes still occupy the SIMD) */
+        const long cost = (long)nby * r * 1000 / 1 + (long)(kBlock - gg * *cbx);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && r > *R)) {
+            best_cost = cost;
+            *R = r;
+            *groups = gg;
+            *ncby = nby;
+        }
+    }
+}
+
+int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
+{
+    if (w->n_theta < 1 || w->n_points < 1 || w->win_x < 0 || w->win_y < 0 ||
+        w->low_resolution < 1)
+        return fail(ctx, CSM_EINVAL, "bad window");
+    p->n_theta = w->n_theta;
+    p->n = w->n_points;
+    p->win_x = w->win_x;
+    p->win_y = w->win_y;
+    p->L = w->low_resolution;
+    p->nxc = ceil_div(2 * w->win_x + 1, p->L);
+    p->nyc = ceil_div(2 * w->win_y + 1, p->L);
+    p->nx = p->nxc * p->L;
+    p->ny = p->nyc * p->L;
+    p->x_lo = -w->win_x;
+    p->y_lo = -w->win_y;
+    p->x_hi = p->x_lo + p->nx - 1;
+    p->y_hi = p->y_lo + p->ny - 1;
+    plan_blocks(p->nx, p->ny, 1, &p->cbx, &p->groups, &p->R, &p->ncbx, &p->ncby, false);
+    const int need = kTile + 7 + p->cbx;
+    p->lstride = need <= 64 ? 64 : need <= 96 ? 96 : need <= 128 ? 128 : 160;
+    if (need > 160)
+        return fail(ctx, CSM_EINVAL, "internal: candidate block too wide");
+    /* coarse pass: candidates L cells apart, must fit the same LDS pitch */
+    p->c_cbx = std::min(p->nxc, (p->lstride - kTile - 8) / p->L + 1);
+    p->c_ncbx = ceil_div(p->nxc, p->c_cbx);
+    p->c_cbx = ceil_div(p->nxc, p->c_ncbx);
+    int cg = std::max(1, kBlock / p->c_cbx);
+    cg = std::min(cg, 64 / p->L + 1);
+    cg = std::min(cg, p->nyc);
+    p->c_groups = cg;
+    p->c_ncby = ceil_div(p->nyc, cg);
+    p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
+    p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi, kTile);
+    p->max_tiles = std::min(p->n, p->tiles_x * p->tiles_y);
+    const size_t bin_lds = (2 * (size_t)p->tiles_x * p->tiles_y + 2 * kBlock) * 4;
+    if (bin_lds > 160 * 1024)
+        return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
+    return CSM_OK;
+}
+
+template <typename K>
+int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)bytes));
+    return CSM_OK;
+}
+
+#define LAUNCH_SCORE(LS, RR, ST)                                                      \
+    do {                                                                              \
+        int rc_ = set_lds(ctx, k_score<LS, RR, ST>, lds);                             \
+        if (rc_)                                                                      \
+            return rc_;                                                               \
+        hipLaunchKernelGGL((k_score<LS, RR, ST>), grid, dim3(kBlock), lds,            \
+                           ctx->stream, job, cbx, groups);                            \
+    } while (0)
+
+#define DISPATCH_R(LS)                                                                \
+    switch (R) {                                                                      \
+    case 4: LAUNCH_SCORE(LS, 4, false); break;                                        \
+    case 5: LAUNCH_SCORE(LS, 5, false); break;                                        \
+    case 6: LAUNCH_SCORE(LS, 6, false); break;                                        \
+    case 7: LAUNCH_SCORE(LS, 7, false); break;                                        \
+    case 8: LAUNCH_SCORE(LS, 8, false); break;                                        \
+    default: return fail(ctx, CSM_EINVAL, "internal: R");                             \
+    }
+
+int launch_score(csm_ctx* ctx, const ScoreJob& job, int lstride, int R, bool strided,
+                 int cbx, int groups, int ncb, int n_theta)
+{
+    const dim3 grid(ncb, n_theta, 1);
+    const int stride = strided ? job.stride : 1;
+    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 2;
+    if (lds > 160 * 1024 - 256)
+        return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
+    if (strided) {
+        switch (lstride) {
+        case 64: LAUNCH_SCORE(64, 1, true); break;
+        case 96: LAUNCH_SCORE(96, 1, true); break;
+        case 128: LAUNCH_SCORE(128, 1, true); break;
+        case 160: LAUNCH_SCORE(160, 1, true); break;
+        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
+        }
+    } else {
+        switch (lstride) {
+        case 64: DISPATCH_R(64); break;
+        case 96: DISPATCH_R(96); break;
+        case 128: DISPATCH_R(128); break;
+        case 160: DISPATCH_R(160); break;
+        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
+DeviceGrid* find_grid(csm_ctx* ctx, uint64_t id)
+{
+    auto it = ctx->grids.find(id);
+    return it == ctx->grids.end() ? nullptr : &it->second;
+}
+
+void free_levels(DeviceGrid& g, bool keep_base)
+{
+    for (size_t i = keep_base ? 1 : 0; i < g.levels.size(); ++i)
+        if (g.levels[i].owned && g.levels[i].cells)
+            (void)hipFree(g.levels[i].cells);
+    g.levels.resize(keep_base && !g.levels.empty() ? 1 : 0);
+}
+
+int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out)
+{
+    if (win < 1 || win > g.rows || win > g.cols)
+        return fail(ctx, CSM_EINVAL, "box-max window %d does not fit %dx%d", win, g.rows, g.cols);
+    const size_t bytes = (size_t)g.rows * g.pitch * 2;
+    int rc = ensure(ctx, ctx->scratch, bytes);
+    if (rc)
+        return rc;
+    uint16_t* dst = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dst), bytes) != hipSuccess)
+        return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    const dim3 grid(ceil_div(g.pitch, kBlock), g.rows);
+    {
+        ScopedTimer tm(ctx, "boxmax");
+        hipLaunchKernelGGL(k_boxmax_v, grid, dim3(kBlock), 0, ctx->stream, g.levels[0].cells,
+                           reinterpret_cast<uint16_t*>(ctx->scratch.p), g.rows, g.cols, g.pitch, win);
+        hipLaunchKernelGGL(k_boxmax_h, grid, dim3(kBlock), 0, ctx->stream,
+                           reinterpret_cast<const uint16_t*>(ctx->scratch.p), dst, g.rows, g.cols,
+                           g.pitch, win);
+    }
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(dst);
+        return fail(ctx, CSM_EIO, "box-max launch failed");
+    }
+    out->win = win;
+    out->cells = dst;
+    out->owned = true;
+    return CSM_OK;
+}
+
+/* index of the level with this window; builds and appends it if missing */
+int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index)
+{
+    for (size_t i = 0; i < g.levels.size(); ++i)
+        if (g.levels[i].win == win) {
+            *index = (int)i;
+            return CSM_OK;
+        }
+    Level lv;
+    int rc = build_level(ctx, g, win, &lv);
+    if (rc)
+        return rc;
+    g.levels.push_back(lv);
+    *index = (int)g.levels.size() - 1;
+    return CSM_OK;
+}
+
+struct WindowOutputs {
+    uint32_t* dump_s = nullptr;     /* device */
+    uint16_t* dump_k = nullptr;
+};
+
+/* The CSM pipeline on device-resident inputs; asynchronous. */
+int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
+               const int32_t* hit_col_dev, const int32_t* hit_row_dev,
+               csm_result* out_dev, const WindowOutputs* dumps)
+{
+    if (w->coarse_level < 0 || w->coarse_level >= (int)g.levels.size())
+        return fail(ctx, CSM_ENOENT, "coarse level %d not built", w->coarse_level);
+    if (g.levels[w->coarse_level].win != p.L)
+        return fail(ctx, CSM_EINVAL, "level %d holds box-max(%d), window asks L=%d",
+                    w->coarse_level, g.levels[w->coarse_level].win, p.L);
+    int rc;
+    const size_t nt = p.n_theta;
+    if ((rc = ensure(ctx, ctx->sorted, nt * p.n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->tiles, nt * p.max_tiles * sizeof(TileRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->ntiles, nt * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->misc, 256))) return rc;
+    if ((rc = ensure(ctx, ctx->coarse_s, nt * p.nxc * p.nyc * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->coarse_k, nt * p.nxc * p.nyc * 2))) return rc;
+    const int ncb = p.ncbx * p.ncby;
+    if ((rc = ensure(ctx, ctx->best, nt * ncb * sizeof(BlockBest)))) return rc;
+
+    uint32_t* flags = reinterpret_cast<uint32_t*>(ctx->misc.p);
+    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 4, ctx->stream));
+
+    BinJob bj;
+    std::memset(&bj, 0, sizeof(bj));
+    bj.hit_col = hit_col_dev;
+    bj.hit_row = hit_row_dev;
+    bj.sorted_pb = reinterpret_cast<uint32_t*>(ctx->sorted.p);
+    bj.tiles = reinterpret_cast<TileRec*>(ctx->tiles.p);
+    bj.n_tiles = reinterpret_cast<int32_t*>(ctx->ntiles.p);
+    bj.flags = flags;
+    bj.n_theta = p.n_theta;
+    bj.n_points = p.n;
+    bj.max_tiles = p.max_tiles;
+    bj.rows = g.rows;
+    bj.cols = g.cols;
+    bj.x_lo = p.x_lo;
+    bj.y_lo = p.y_lo;
+    bj.x_hi = p.x_hi;
+    bj.y_hi = p.y_hi;
+    bj.tiles_x = p.tiles_x;
+    bj.tiles_y = p.tiles_y;
+    bj.lstride = p.lstride;
+    if (p.L > 1) {
+        bj.n_band = 1;
+        bj.band_win[0] = p.L;
+        bj.band_nx[0] = p.nxc;
+        bj.band_ny[0] = p.nyc;
+    }
+    {
+        const size_t lds = (2 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4;
+        if ((rc = set_lds(ctx, k_bin, lds))) return rc;
+        ScopedTimer tm(ctx, "bin");
+        hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBlock), lds, ctx->stream, bj);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+
+    ScoreJob base;
+    std::memset(&base, 0, sizeof(base));
+    base.rows = g.rows;
+    base.cols = g.cols;
+    base.pitch = g.pitch;
+    base.sorted_pb = bj.sorted_pb;
+    base.tiles = bj.tiles;
+    base.n_tiles = bj.n_tiles;
+    base.n_theta = p.n_theta;
+    base.n_points = p.n;
+    base.max_tiles = p.max_tiles;
+    base.x_lo = p.x_lo;
+    base.y_lo = p.y_lo;
+    base.flags = flags;
+    base.min_known = w->min_known;
+
+    if (p.L > 1) {
+        ScoreJob cj = base;
+        cj.cells = g.levels[w->coarse_level].cells;
+        cj.nx = p.nxc;
+        cj.ny = p.nyc;
+        cj.stride = p.L;
+        cj.dump_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
+        cj.dump_k = reinterpret_cast<uint16_t*>(ctx->coarse_k.p);
+        cj.rank_l = 1;
+        ScopedTimer tm(ctx, "score_coarse");
+        if ((rc = launch_score(ctx, cj, p.lstride, 1, true, p.c_cbx, p.c_groups,
+                               p.c_ncbx * p.c_ncby, p.n_theta)))
+            return rc;
+    }
+
+    ScoreJob fj = base;
+    fj.cells = g.levels[0].cells;
+    fj.nx = p.nx;
+    fj.ny = p.ny;
+    fj.stride = 1;
+    fj.block_best = reinterpret_cast<BlockBest*>(ctx->best.p);
+    fj.rank_l = p.L;
+    if (dumps) {
+        fj.dump_s = dumps->dump_s;
+        fj.dump_k = dumps->dump_k;
+    }
+    if (p.L > 1) {
+        fj.n_elig = 1;
+        fj.elig[0].k = reinterpret_cast<const uint16_t*>(ctx->coarse_k.p);
+        fj.elig[0].s = reinterpret_cast<const uint32_t*>(ctx->coarse_s.p);
+        fj.elig[0].div = p.L;
+        fj.elig[0].nxc = p.nxc;
+        fj.elig[0].nyc = p.nyc;
+    } else {
+        fj.check_own_known = 1;
+    }
+    {
+        ScopedTimer tm(ctx, "score_fine");
+        if ((rc = launch_score(ctx, fj, p.lstride, p.R, false, p.cbx, p.groups, ncb, p.n_theta)))
+            return rc;
+    }
+
+    FinalJob fin;
+    std::memset(&fin, 0, sizeof(fin));
+    fin.block_best = fj.block_best;
+    fin.n_entries = p.n_theta * ncb;
+    fin.nx = p.nx;
+    fin.ny = p.ny;
+    fin.rank_l = p.L;
+    fin.x_lo = p.x_lo;
+    fin.y_lo = p.y_lo;
+    fin.win_theta = (p.n_theta - 1) / 2;
+    fin.init_x = -p.win_x;
+    fin.init_y = -p.win_y;
+    fin.init_theta = -fin.win_theta;
+    fin.cells = g.levels[0].cells;
+    fin.rows = g.rows;
+    fin.cols = g.cols;
+    fin.pitch = g.pitch;
+    fin.hit_col = hit_col_dev;
+    fin.hit_row = hit_row_dev;
+    fin.n_points = p.n;
+    fin.score_thr = w->score_threshold;
+    fin.lut = ctx->lut_dev;
+    fin.flags_in = flags;
+    fin.out = out_dev;
+    {
+        const size_t lds = (size_t)p.n * 8;
+        if ((rc = set_lds(ctx, k_finalize, lds))) return rc;
+        ScopedTimer tm(ctx, "finalize");
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), lds, ctx->stream, fin);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return CSM_OK;
+}
+
+} /* namespace */
+
+/* ------------------------------------------------------------------ C ABI */
+
+extern "C" {
+
+const char* csm_version(void) { return "csm_hip 0.1 (gfx950)"; }
+
+int csm_create(const csm_config* cfg, csm_ctx** out)
+{
+    if (!out)
+        return CSM_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return CSM_ENODEV;
+    const int dev = cfg ? cfg->device_id : 0;
+    if (dev < 0 || dev >= ndev)
+        return CSM_ENODEV;
+    csm_ctx* ctx = new csm_ctx();
+    ctx->device = dev;
+    if (hipSetDevice(dev) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return CSM_ENODEV;
+    }
+    ctx->stream = ctx->own_stream;
+    std::vector<double> lut(65536);
+    csm_host_probability_lut(lut.data());
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->lut_dev), 65536 * 8) != hipSuccess ||
+        hipMemcpy(ctx->lut_dev, lut.data(), 65536 * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        delete ctx;
+        return CSM_ENOMEM;
+    }
+    *out = ctx;
+    return CSM_OK;
+}
+
+int csm_destroy(csm_ctx* ctx)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->grids)
+        free_levels(kv.second, false);
+    DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
+                       &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
+                       &ctx->scratch };
+    for (DevBuf* b : bufs)
+        if (b->p)
+            (void)hipFree(b->p);
+    if (ctx->lut_dev)
+        (void)hipFree(ctx->lut_dev);
+    for (auto& kv : ctx->timers)
+        for (auto& s : kv.second.spans) {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+    for (hipEvent_t e : ctx->event_pool)
+        (void)hipEventDestroy(e);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return CSM_OK;
+}
+
+const char* csm_last_error(const csm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int csm_set_stream(csm_ctx* ctx, void* hip_stream)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return CSM_OK;
+}
+
+int csm_synchronize(csm_ctx* ctx)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CSM_OK;
+}
+
+int csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense, int32_t rows, int32_t cols)
+{
+    if (!ctx || !dense || rows < 1 || cols < 1)
+        return fail(ctx, CSM_EINVAL, "csm_upload_grid: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGrid& g = ctx->grids[map_id];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(g, false);
+    g.rows = rows;
+    g.cols = cols;
+    g.pitch = (cols + 7) & ~7;
+    Level base;
+    const size_t bytes = (size_t)rows * g.pitch * 2;
+    if (hipMalloc(reinterpret_cast<void**>(&base.cells), bytes) != hipSuccess) {
+        ctx->grids.erase(map_id);
+        return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    }
+    base.win = 1;
+    base.owned = true;
+    g.levels.push_back(base);
+    HIP_TRY(ctx, hipMemsetAsync(base.cells, 0, bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(base.cells, (size_t)g.pitch * 2, dense, (size_t)cols * 2,
+                                  (size_t)cols * 2, rows, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CSM_OK;
+}
+
+int csm_has_grid(csm_ctx* ctx, uint64_t map_id)
+{
+    return ctx && find_grid(ctx, map_id) ? 1 : 0;
+}
+
+int csm_release_grid(csm_ctx* ctx, uint64_t map_id)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(*g, false);
+    ctx->grids.erase(map_id);
+    return CSM_OK;
+}
+
+int csm_build_pyramid(csm_ctx* ctx, uint64_t map_id, const int32_t* win_sizes, int32_t n_levels)
+{
+    if (!ctx || !win_sizes || n_levels < 1)
+        return fail(ctx, CSM_EINVAL, "csm_build_pyramid: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (win_sizes[0] != 1)
+        return fail(ctx, CSM_EINVAL, "win_sizes[0] must be 1 (level 0 is the grid itself)");
+    free_levels(*g, true);
+    std::vector<Level> lv;
+    lv.push_back(g->levels[0]);
+    for (int i = 1; i < n_levels; ++i) {
+        Level l;
+        if (win_sizes[i] == 1) {
+            l = g->levels[0];
+            l.owned = false;
+        } else {
+            int rc = build_level(ctx, *g, win_sizes[i], &l);
+            if (rc) {
+                for (size_t j = 1; j < lv.size(); ++j)
+                    if (lv[j].owned)
+                        (void)hipFree(lv[j].cells);
+                return rc;
+            }
+        }
+        lv.push_back(l);
+    }
+    g->levels = lv;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CSM_OK;
+}
+
+int csm_download_level(csm_ctx* ctx, uint64_t map_id, int32_t level, uint16_t* out)
+{
+    if (!ctx || !out)
+        return fail(ctx, CSM_EINVAL, "csm_download_level: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g || level < 0 || level >= (int)g->levels.size())
+        return fail(ctx, CSM_ENOENT, "map %llu level %d not resident",
+                    (unsigned long long)map_id, level);
+    HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)g->cols * 2, g->levels[level].cells,
+                                  (size_t)g->pitch * 2, (size_t)g->cols * 2, g->rows,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CSM_OK;
+}
+
+/* ---- host set-up pieces ---- */
+
+int csm_host_search_step(double resolution, const double* ranges, int32_t n,
+                         double* step_x, double* step_y, double* step_theta)
+{
+    if (!ranges || n < 1)
+        return CSM_EINVAL;
+    const double max_range = *std::max_element(ranges, ranges + n);
+    const double theta = resolution / max_range;
+    *step_x = resolution;
+    *step_y = resolution;
+    *step_theta = std::acos(1.0 - 0.5 * theta * theta);
+    return CSM_OK;
+}
+
+int csm_host_window(double range, double step)
+{
+    return static_cast<int>(std::ceil(0.5 * range / step));
+}
+
+int csm_host_min_known(int32_t n_points, double thr)
+{
+    /* smallest K in [0, n+1] with double(K)/double(n) > thr (monotone in K) */
+    int lo = 0, hi = n_points + 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (static_cast<double>(mid) / static_cast<double>(n_points) > thr)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+void csm_host_compound(const double s[3], const double d[3], double out[3])
+{
+    const double sin_t = std::sin(s[2]);
+    const double cos_t = std::cos(s[2]);
+    const double x = cos_t * d[0] - sin_t * d[1] + s[0];
+    const double y = sin_t * d[0] + cos_t * d[1] + s[1];
+    const double th = s[2] + d[2];
+    out[0] = x;
+    out[1] = y;
+    out[2] = th;
+}
+
+void csm_host_inverse_compound(const double s[3], const double e[3], double out[3])
+{
+    const double sin_t = std::sin(s[2]);
+    const double cos_t = std::cos(s[2]);
+    const double dx = e[0] - s[0];
+    const double dy = e[1] - s[1];
+    const double dt = e[2] - s[2];
+    out[0] = cos_t * dx + sin_t * dy;
+    out[1] = -sin_t * dx + cos_t * dy;
+    out[2] = dt;
+}
+
+void csm_host_move_backward(const double e[3], const double d[3], double out[3])
+{
+    const double th = e[2] - d[2];
+    const double sin_t = std::sin(th);
+    const double cos_t = std::cos(th);
+    const double x = e[0] - cos_t * d[0] + sin_t * d[1];
+    const double y = e[1] - sin_t * d[0] - cos_t * d[1];
+    out[0] = x;
+    out[1] = y;
+    out[2] = th;
+}
+
+int csm_host_project(const csm_geometry* geom, const double sensor_pose[3], double step_theta,
+                     int32_t win_theta, const double* angles, const double* ranges, int32_t n,
+                     int32_t* hit_col, int32_t* hit_row, double* r_cos, double* r_sin)
+{
+    if (!geom || !sensor_pose || !angles || !ranges || n < 1 || win_theta < 0 || !hit_col || !hit_row)
+        return CSM_EINVAL;
+    for (int t = -win_theta; t <= win_theta; ++t) {
+        const double theta = sensor_pose[2] + step_theta * t;
+        const size_t base = (size_t)(t + win_theta) * n;
+        for (int i = 0; i < n; ++i) {
+            /* ScanData::HitPoint, inc/sensor/sensor_data.hpp:189-203 */
+            const double cos_t = std::cos(theta + angles[i]);
+            const double sin_t = std::sin(theta + angles[i]);
+            const double rc = ranges[i] * cos_t;
+            const double rs = ranges[i] * sin_t;
+            const double hx = sensor_pose[0] + rc;
+            const double hy = sensor_pose[1] + rs;
+            /* PositionToIndex, src/grid_map_new/grid_map_geometry.cpp:113-122 */
+            hit_col[base + i] = static_cast<int>(std::floor((hx - geom->offset_x) / geom->resolution));
+            hit_row[base + i] = static_cast<int>(std::floor((hy - geom->offset_y) / geom->resolution));
+            if (r_cos)
+                r_cos[base + i] = rc;
+            if (r_sin)
+                r_sin[base + i] = rs;
+        }
+    }
+    return CSM_OK;
+}
+
+void csm_host_probability_lut(double* lut)
+{
+    for (unsigned v = 0; v < 65536; ++v)
+        lut[v] = value_to_probability(v);
+}
+
+/* ---- hot path ---- */
+
+int csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
+                         const int32_t* hit_col_dev, const int32_t* hit_row_dev, csm_result* out_dev)
+{
+    if (!ctx || !w || !hit_col_dev || !hit_row_dev || !out_dev)
+        return fail(ctx, CSM_EINVAL, "csm_score_window_dev: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Plan p;
+    int rc = make_plan(ctx, *g, w, &p);
+    if (rc)
+        return rc;
+    return run_window(ctx, *g, w, p, hit_col_dev, hit_row_dev, out_dev, nullptr);
+}
+
+int csm_score_window_dump(csm_ctx* ctx, uint64_t map_id, const csm_window* w, const int32_t* hit_col,
+                          const int32_t* hit_row, csm_result* out, uint32_t* dump_s,
+                          uint16_t* dump_k, uint16_t* dump_coarse_k)
+{
+    if (!ctx || !w || !hit_col || !hit_row || !out)
+        return fail(ctx, CSM_EINVAL, "csm_score_window: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Plan p;
+    int rc = make_plan(ctx, *g, w, &p);
+    if (rc)
+        return rc;
+    const size_t hn = (size_t)p.n_theta * p.n;
+    if ((rc = ensure(ctx, ctx->hits, hn * 8 + 256))) return rc;
+    int32_t* col_dev = reinterpret_cast<int32_t*>(ctx->hits.p);
+    int32_t* row_dev = col_dev + hn;
+    csm_result* res_dev = reinterpret_cast<csm_result*>(row_dev + hn);
+    HIP_TRY(ctx, hipMemcpyAsync(col_dev, hit_col, hn * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(row_dev, hit_row, hn * 4, hipMemcpyHostToDevice, ctx->stream));
+    WindowOutputs dumps;
+    const size_t nc = (size_t)p.n_theta * p.nx * p.ny;
+    if (dump_s) {
+        if ((rc = ensure(ctx, ctx->dump_s, nc * 4))) return rc;
+        dumps.dump_s = reinterpret_cast<uint32_t*>(ctx->dump_s.p);
+    }
+    if (dump_k) {
+        if ((rc = ensure(ctx, ctx->dump_k, nc * 2))) return rc;
+        dumps.dump_k = reinterpret_cast<uint16_t*>(ctx->dump_k.p);
+    }
+    rc = run_window(ctx, *g, w, p, col_dev, row_dev, res_dev, (dump_s || dump_k) ? &dumps : nullptr);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (dump_s)
+        HIP_TRY(ctx, hipMemcpyAsync(dump_s, dumps.dump_s, nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (dump_k)
+        HIP_TRY(ctx, hipMemcpyAsync(dump_k, dumps.dump_k, nc * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (dump_coarse_k && p.L > 1)
+        HIP_TRY(ctx, hipMemcpyAsync(dump_coarse_k, ctx->coarse_k.p, (size_t)p.n_theta * p.nxc * p.nyc * 2,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CSM_OK;
+}
+
+int csm_score_window(csm_ctx* ctx, uint64_t map_id, const csm_window* w, const int32_t* hit_col,
+                     const int32_t* hit_row, csm_result* out)
+{
+    return csm_score_window_dump(ctx, map_id, w, hit_col, hit_row, out, nullptr, nullptr, nullptr);
+}
+
+int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geom,
+                          const csm_scan* scan, const double initial_pose[3],
+                          const csm_correlative_params* prm, csm_summary* out)
+{
+    if (!ctx || !geom || !scan || !initial_pose || !prm || !out || scan->n_points < 1 ||
+        prm->low_resolution < 1)
+        return fail(ctx, CSM_EINVAL, "csm_correlative_match: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof(*out));
+    const auto t0 = std::chrono::steady_clock::now();
+    int level = 0;
+    int rc = level_for_window(ctx, *g, prm->low_resolution, &level);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+
+    /* scan_matcher_correlative.cpp:130-146 */
+    csm_host_compound(initial_pose, scan->relative_sensor_pose, out->sensor_pose);
+    csm_host_search_step(geom->resolution, scan->ranges, scan->n_points, &out->step_x,
+                         &out->step_y, &out->step_theta);
+    out->win_x = csm_host_window(prm->range_x, out->step_x);
+    out->win_y = csm_host_window(prm->range_y, out->step_y);
+    out->win_theta = csm_host_window(prm->range_theta, out->step_theta);
+
+    csm_window w;
+    std::memset(&w, 0, sizeof(w));
+    w.n_theta = 2 * out->win_theta + 1;
+    w.n_points = scan->n_points;
+    w.win_x = out->win_x;
+    w.win_y = out->win_y;
+    w.low_resolution = prm->low_resolution;
+    w.coarse_level = level;
+    w.min_known = csm_host_min_known(scan->n_points, prm->known_rate_threshold);
+    w.score_threshold = prm->score_threshold;
+
+    const size_t hn = (size_t)w.n_theta * w.n_points;
+    std::vector<int32_t> col(hn), row(hn);
+    rc = csm_host_project(geom, out->sensor_pose, out->step_theta, out->win_theta, scan->angles,
+                          scan->ranges, scan->n_points, col.data(), row.data(), nullptr, nullptr);
+    if (rc)
+        return fail(ctx, rc, "projection failed");
+    rc = csm_score_window(ctx, map_id, &w, col.data(), row.data(), &out->raw);
+    if (rc)
+        return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+
+    out->pose_found = out->raw.found;
+    /* scan_matcher_correlative.cpp:203-206, 214-216 */
+    out->best_sensor_pose[0] = out->sensor_pose[0] + out->raw.best_x * out->step_x;
+    out->best_sensor_pose[1] = out->sensor_pose[1] + out->raw.best_y * out->step_y;
+    out->best_sensor_pose[2] = out->sensor_pose[2] + out->raw.best_theta * out->step_theta;
+    csm_host_move_backward(out->best_sensor_pose, scan->relative_sensor_pose, out->estimated_pose);
+    const int nx = ceil_div(2 * w.win_x + 1, w.low_resolution) * w.low_resolution;
+    const int ny = ceil_div(2 * w.win_y + 1, w.low_resolution) * w.low_resolution;
+    out->candidates = (int64_t)w.n_theta * nx * ny;
+    out->input_setup_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    out->optimization_us = std::chrono::duration<double, std::micro>(t2 - t1).count();
+    return CSM_OK;
+}
+
+int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_queries,
+                        const csm_bnb_params* params, csm_summary* out)
+{
+    (void)queries;
+    (void)n_queries;
+    (void)params;
+    (void)out;
+    return fail(ctx, CSM_EINVAL, "csm_bnb_match_batch: not built yet");
+}
+
+/* ---- measurement hooks ---- */
+
+int csm_enable_kernel_timing(csm_ctx* ctx, int32_t enable)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    ctx->timing = enable != 0;
+    return CSM_OK;
+}
+
+static void drain_timer(csm_ctx* ctx, KernelTimer& kt)
+{
+    for (auto& s : kt.spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            kt.total_ms += ms;
+            kt.launches += 1;
+        }
+        ctx->event_pool.push_back(s.a);
+        ctx->event_pool.push_back(s.b);
+    }
+    kt.spans.clear();
+}
+
+int csm_kernel_time(csm_ctx* ctx, const char* name, double* total_ms, int64_t* launches)
+{
+    if (!ctx || !name)
+        return CSM_EINVAL;
+    auto it = ctx->timers.find(name);
+    if (it == ctx->timers.end()) {
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = 0;
+        return CSM_OK;
+    }
+    drain_timer(ctx, it->second);
+    if (total_ms) *total_ms = it->second.total_ms;
+    if (launches) *launches = it->second.launches;
+    return CSM_OK;
+}
+
+int csm_reset_kernel_timing(csm_ctx* ctx)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    for (auto& kv : ctx->timers) {
+        drain_timer(ctx, kv.second);
+        kv.second.total_ms = 0.0;
+        kv.second.launches = 0;
+    }
+    return CSM_OK;
+}
+
+} /* extern "C" */

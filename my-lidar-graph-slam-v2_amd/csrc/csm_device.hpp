@@ -1,0 +1,103 @@
+/* csm_device.hpp -- device-side data structures shared by the kernels and the
+ * host launcher of libcsm_hip (gfx950 only). */
+#ifndef CSM_DEVICE_HPP
+#define CSM_DEVICE_HPP
+
+#include <stdint.h>
+
+namespace csm {
+
+constexpr int kTile = 32;        /* endpoint tile edge, cells */
+constexpr int kBlock = 256;      /* threads per workgroup (4 wave64) */
+constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
+/* internal flag bit (never returned): some beam can reach the negative edge
+ * band of a coarser level for some candidate offset */
+constexpr uint32_t kFlagBandTouch = 1u << 16;
+
+/* One non-empty endpoint tile of one theta slice. */
+struct TileRec {
+    int32_t  r0, c0;     /* grid row / col of the tile's first cell */
+    uint32_t start;      /* first beam in the slice's sorted list */
+    uint32_t count;
+};
+
+/* Best candidate of one workgroup (or of a reduction of several). */
+struct BlockBest {
+    unsigned long long key;    /* 0 = no eligible candidate */
+    unsigned long long rank;   /* traversal rank of the first best candidate */
+    uint32_t count;            /* candidates sharing `key` */
+    uint32_t pad;
+};
+
+/* Known-count array of a coarser level: K[t][xi / div][yi / div]. */
+struct EligLevel {
+    const uint16_t* k;
+    const uint32_t* s;         /* raw-value sums of the same nodes (bound check) */
+    int32_t div;
+    int32_t nxc, nyc;
+};
+
+/* Bin the beams of every theta slice by endpoint tile. */
+struct BinJob {
+    const int32_t* hit_col;    /* [n_theta][n_points] */
+    const int32_t* hit_row;
+    uint32_t* sorted_pb;       /* [n_theta][n_points] packed LDS offsets */
+    TileRec*  tiles;           /* [n_theta][max_tiles] */
+    int32_t*  n_tiles;         /* [n_theta] */
+    uint32_t* flags;           /* [1] CSM_FLAG_* accumulated with atomicOr */
+    int32_t n_theta, n_points, max_tiles;
+    int32_t rows, cols;
+    int32_t x_lo, y_lo;        /* most negative candidate offset */
+    int32_t x_hi, y_hi;        /* most positive candidate offset */
+    int32_t tiles_x, tiles_y;
+    int32_t lstride;
+    /* edge-band detection: coarse strides to test (box windows) */
+    int32_t n_band;
+    int32_t band_win[kMaxElig];
+    int32_t band_nx[kMaxElig], band_ny[kMaxElig];
+};
+
+/* Score every candidate of one level of one query. */
+struct ScoreJob {
+    const uint16_t* cells;     /* pitched grid level */
+    int32_t rows, cols, pitch;
+    const uint32_t* sorted_pb;
+    const TileRec*  tiles;
+    const int32_t*  n_tiles;
+    int32_t n_theta, n_points, max_tiles;
+    int32_t x_lo, y_lo;        /* cell offset of candidate index 0 */
+    int32_t nx, ny;            /* candidates per axis */
+    int32_t stride;            /* cells between neighbouring candidates */
+    /* outputs (any may be null) */
+    uint32_t*  dump_s;         /* [n_theta][nx][ny] */
+    uint16_t*  dump_k;         /* [n_theta][nx][ny] */
+    BlockBest* block_best;     /* [n_theta][n_cand_blocks] */
+    uint32_t*  flags;          /* [1] query flags (band touch in, edge band out) */
+    /* eligibility for the argmax */
+    int32_t n_elig;
+    int32_t min_known;
+    int32_t check_own_known;   /* also require the candidate's own K >= min_known */
+    int32_t rank_l;            /* L of the traversal rank (1: plain t,x,y order) */
+    EligLevel elig[kMaxElig];
+};
+
+/* Reduce block results, replay the winner in f64, write the result record. */
+struct FinalJob {
+    const BlockBest* block_best;
+    int32_t n_entries;
+    int32_t nx, ny, rank_l;
+    int32_t x_lo, y_lo, win_theta;
+    int32_t init_x, init_y, init_theta;   /* reported when nothing is found */
+    const uint16_t* cells;
+    int32_t rows, cols, pitch;
+    const int32_t* hit_col;
+    const int32_t* hit_row;
+    int32_t n_points;
+    double score_thr;
+    const double* lut;
+    const uint32_t* flags_in;
+    void* out;                 /* csm_result* (device) */
+};
+
+} /* namespace csm */
+#endif

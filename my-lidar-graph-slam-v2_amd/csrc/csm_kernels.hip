@@ -1,0 +1,486 @@
+/* csm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the
+ * correlative scan-matching hot path.
+ *
+ * K0 k_bin       bins the beams of one theta slice by 32x32-cell endpoint tile
+ *                (LDS counting sort), emits packed LDS offsets per beam.
+ * K1 k_score     one workgroup = (theta slice, block of candidate offsets):
+ *                for every non-empty endpoint tile it stages tile + window halo
+ *                of the uint16 grid into LDS with 16-byte coalesced loads, then
+ *                every lane walks the tile's beams and gathers from LDS for its
+ *                own R candidate offsets, accumulating exact integer (S, K).
+ *                Ends in a wave64 shuffle arg-max, one record per workgroup.
+ *                Replaces ComputeScore inside the sweep of
+ *                src/mapping/scan_matcher_correlative.cpp:161-197, 301-368 and
+ *                ScorePixelAccurate::Score per branch-and-bound node
+ *                (src/mapping/score_function_pixel_accurate.cpp:16-58).
+ * K2 k_boxmax_*  forward box maximum with the reference's "repeat the last
+ *                window" edge rule (inc/util.hpp:369-424,
+ *                src/mapping/grid_map_builder.cpp:918-984).
+ * K4 k_finalize  reduces the workgroup records, replays the winner in f64 in
+ *                beam order (bit-exact scoreMax), writes the result record.
+ *
+ * Integer order key: sum P = (0.998/65534/499) * (32268*K + 499*S) with
+ * S = sum of raw values over known cells, K = known count, so the u64 key
+ * orders candidates exactly like the reference's double sum whenever keys
+ * differ.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "csm_device.hpp"
+#include "../../include/csm_hip.h"
+
+namespace csm {
+
+__device__ __forceinline__ int floor_div(int a, int b)
+{
+    int q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0)))
+        --q;
+    return q;
+}
+
+/* Is there k in [0, nk) with -(w-1) <= u + k*w <= -1 ?  Returns k or -1. */
+__device__ __forceinline__ int band_index(int u, int w, int nk)
+{
+    const int k0 = floor_div(-u, w);
+    if (k0 < 0 || k0 >= nk)
+        return -1;
+    const int v = u + k0 * w;
+    return (v <= -1 && v >= -(w - 1)) ? k0 : -1;
+}
+
+/* ------------------------------------------------------------------ K0 */
+__global__ __launch_bounds__(kBlock) void k_bin(BinJob job)
+{
+    extern __shared__ uint32_t sm_bin[];
+    const int ntile = job.tiles_x * job.tiles_y;
+    uint32_t* hist = sm_bin;            /* [ntile] counts, later cursors */
+    uint32_t* first = sm_bin + ntile;   /* [ntile] start offsets */
+    uint32_t* part = first + ntile;     /* [2 * kBlock] */
+    const int t = blockIdx.x;
+    if (t >= job.n_theta)
+        return;
+    const int tid = threadIdx.x;
+    const int n = job.n_points;
+    const int32_t* col = job.hit_col + (size_t)t * n;
+    const int32_t* row = job.hit_row + (size_t)t * n;
+
+    for (int i = tid; i < ntile; i += kBlock)
+        hist[i] = 0;
+    __syncthreads();
+
+    const int r_max = job.rows - 1 - job.y_lo;
+    const int c_max = job.cols - 1 - job.x_lo;
+    bool band = false;
+    for (int i = tid; i < n; i += kBlock) {
+        const int r = row[i], c = col[i];
+        const int rr = r + job.y_hi, cc = c + job.x_hi;
+        if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max)
+            atomicAdd(&hist[(rr / kTile) * job.tiles_x + cc / kTile], 1u);
+        for (int b = 0; b < job.n_band; ++b) {
+            const int w = job.band_win[b];
+            if (band_index(r + job.y_lo, w, job.band_ny[b]) >= 0 ||
+                band_index(c + job.x_lo, w, job.band_nx[b]) >= 0)
+                band = true;
+        }
+    }
+    if (band)
+        atomicOr(job.flags, kFlagBandTouch);
+    __syncthreads();
+
+    /* exclusive scan of counts and of the non-empty flags */
+    const int chunk = (ntile + kBlock - 1) / kBlock;
+    const int lo = tid * chunk, hi = min(lo + chunk, ntile);
+    uint32_t cnt = 0, ne = 0;
+    for (int i = lo; i < hi; ++i) {
+        cnt += hist[i];
+        ne += hist[i] != 0;
+    }
+    part[tid] = cnt;
+    part[kBlock + tid] = ne;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0, b = 0;
+        for (int i = 0; i < kBlock; ++i) {
+            const uint32_t x = part[i], y = part[kBlock + i];
+            part[i] = a;
+            part[kBlock + i] = b;
+            a += x;
+            b += y;
+        }
+        job.n_tiles[t] = (int32_t)b;
+    }
+    __syncthreads();
+    uint32_t off = part[tid], slot = part[kBlock + tid];
+    TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t c = hist[i];
+        first[i] = off;
+        if (c != 0) {
+            TileRec rec;
+            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi;
+            rec.c0 = (i % job.tiles_x) * kTile - job.x_hi;
+            rec.start = off;
+            rec.count = c;
+            recs[slot++] = rec;
+        }
+        off += c;
+    }
+    __syncthreads();
+    for (int i = lo; i < hi; ++i)
+        hist[i] = first[i];
+    __syncthreads();
+
+    uint32_t* out = job.sorted_pb + (size_t)t * n;
+    for (int i = tid; i < n; i += kBlock) {
+        const int r = row[i], c = col[i];
+        const int rr = r + job.y_hi, cc = c + job.x_hi;
+        if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
+            const int ty = rr / kTile, tx = cc / kTile;
+            const uint32_t pos = atomicAdd(&hist[ty * job.tiles_x + tx], 1u);
+            out[pos] = (uint32_t)((rr - ty * kTile) * job.lstride + (cc - tx * kTile));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ K1 */
+
+__device__ __forceinline__ void best_combine(unsigned long long& key,
+                                             unsigned long long& rank,
+                                             uint32_t& count,
+                                             unsigned long long k2,
+                                             unsigned long long r2,
+                                             uint32_t c2)
+{
+    if (k2 > key) {
+        key = k2;
+        rank = r2;
+        count = c2;
+    } else if (k2 == key) {
+        rank = r2 < rank ? r2 : rank;
+        count += c2;
+    }
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+{
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+/* LSTRIDE: LDS row pitch in cells. R: candidate rows per lane.
+ * STRIDED: candidates are `stride` cells apart (coarser levels). */
+template <int LSTRIDE, int R, bool STRIDED>
+__device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
+    __shared__ unsigned long long red_key[kBlock / 64];
+    __shared__ unsigned long long red_rank[kBlock / 64];
+    __shared__ uint32_t red_cnt[kBlock / 64];
+
+    const int t = blockIdx.y;
+    if (t >= job.n_theta)
+        return;
+    const int tid = threadIdx.x;
+    const int stride = STRIDED ? job.stride : 1;
+    const int ncbx = (job.nx + cbx - 1) / cbx;
+    const int bx = blockIdx.x % ncbx, by = blockIdx.x / ncbx;
+    const int cby = groups * R;
+    if (by * cby >= job.ny)
+        return;
+
+    const int dxi = tid % cbx, g = tid / cbx;
+    const bool lane_on = g < groups;
+    /* first candidate offset of this block, in cells */
+    const int x0 = job.x_lo + bx * cbx * stride;
+    const int y0 = job.y_lo + by * cby * stride;
+    const int region_rows = kTile + (cby - 1) * stride;
+    /* lane base inside the region (cells) */
+    const int tb = lane_on ? (g * R * stride) * LSTRIDE + dxi * stride : 0;
+    const int row_step = stride * LSTRIDE;
+
+    uint32_t S[R], K[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        S[r] = 0;
+        K[r] = 0;
+    }
+
+    const int ntiles = job.n_tiles[t];
+    const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
+    const uint32_t* pbs = job.sorted_pb + (size_t)t * job.n_points;
+    constexpr int kChunks = LSTRIDE / 8;
+
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const TileRec rec = recs[ti];
+        const int cs = (rec.c0 + x0) & ~7;          /* 16-byte aligned first col */
+        const int a = (rec.c0 + x0) - cs;           /* 0..7 */
+        const int gr0 = rec.r0 + y0;
+
+        __syncthreads();                            /* previous tile consumed */
+        for (int idx = tid; idx < region_rows * kChunks; idx += kBlock) {
+            const int lr = idx / kChunks, ch = idx - lr * kChunks;
+            const int gr = gr0 + lr, gc = cs + ch * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gr >= 0 && gr < job.rows && gc >= 0 && gc < job.pitch)
+                v = *reinterpret_cast<const uint4*>(job.cells + (size_t)gr * job.pitch + gc);
+            *reinterpret_cast<uint4*>(sm_tile + lr * LSTRIDE + ch * 8) = v;
+        }
+        __syncthreads();
+
+        const uint32_t* pb = pbs + rec.start;
+        const int cnt = (int)rec.count;
+        const uint16_t* base = sm_tile + tb + a;
+#pragma unroll 4
+        for (int b = 0; b < cnt; ++b) {
+            const uint16_t* p = base + pb[b];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t v = STRIDED ? p[r * row_step] : p[r * LSTRIDE];
+                S[r] += v;
+                K[r] += v != 0 ? 1u : 0u;
+            }
+        }
+    }
+
+    /* ---- epilogue: dumps, eligibility, arg-max ---- */
+    const int xi = bx * cbx + dxi;
+    unsigned long long bkey = 0, brank = ~0ull;
+    uint32_t bcnt = 0;
+    bool bound_broken = false;
+    const bool band_touch =
+        job.block_best && job.n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
+    if (lane_on && xi < job.nx) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yi = by * cby + g * R + r;
+            if (yi >= job.ny)
+                continue;
+            const size_t ci = ((size_t)t * job.nx + xi) * job.ny + yi;
+            if (job.dump_s)
+                job.dump_s[ci] = S[r];
+            if (job.dump_k)
+                job.dump_k[ci] = (uint16_t)K[r];
+            if (!job.block_best)
+                continue;
+            bool ok = !job.check_own_known || (int)K[r] >= job.min_known;
+            const unsigned long long key =
+                32268ull * K[r] + 499ull * (unsigned long long)S[r];
+            bool broken = false;
+            for (int e = 0; e < job.n_elig && ok; ++e) {
+                const EligLevel& el = job.elig[e];
+                const size_t ni =
+                    ((size_t)t * el.nxc + xi / el.div) * el.nyc + yi / el.div;
+                const uint32_t ck = el.k[ni];
+                ok = (int)ck >= job.min_known;
+                /* the coarser node must bound this candidate; it can fail to
+                 * only through the negative edge band */
+                const unsigned long long ckey =
+                    32268ull * ck + 499ull * (unsigned long long)el.s[ni];
+                broken |= key > ckey || (key == ckey && band_touch);
+            }
+            if (!ok)
+                continue;
+            bound_broken |= broken;
+            if (key == 0)
+                continue;
+            const int L = job.rank_l;
+            const int nxc = job.nx / L, nyc = job.ny / L;
+            const unsigned long long rank =
+                ((((unsigned long long)t * nxc + xi / L) * nyc + yi / L) * L + xi % L) * L + yi % L;
+            best_combine(bkey, brank, bcnt, key, rank, 1u);
+        }
+    }
+    if (!job.block_best)
+        return;
+    if (bound_broken)
+        atomicOr(job.flags, CSM_FLAG_EDGE_BAND);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long k2 = shfl_xor_u64(bkey, m);
+        const unsigned long long r2 = shfl_xor_u64(brank, m);
+        const uint32_t c2 = __shfl_xor(bcnt, m, 64);
+        best_combine(bkey, brank, bcnt, k2, r2, c2);
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+        red_key[wave] = bkey;
+        red_rank[wave] = brank;
+        red_cnt[wave] = bcnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            best_combine(bkey, brank, bcnt, red_key[w], red_rank[w], red_cnt[w]);
+        BlockBest bb;
+        bb.key = bkey;
+        bb.rank = brank;
+        bb.count = bcnt;
+        bb.pad = 0;
+        job.block_best[(size_t)t * gridDim.x + blockIdx.x] = bb;
+    }
+}
+
+template <int LSTRIDE, int R, bool STRIDED>
+__global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups)
+{
+    score_body<LSTRIDE, R, STRIDED>(job, cbx, groups);
+}
+
+template <int LSTRIDE, int R, bool STRIDED>
+__global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups)
+{
+    score_body<LSTRIDE, R, STRIDED>(jobs[blockIdx.z], cbx, groups);
+}
+
+/* ------------------------------------------------------------------ K2 */
+/* out[r][c] = max_{k<w} in[min(r, rows-w)+k][c]; pad columns stay 0 */
+__global__ __launch_bounds__(kBlock) void k_boxmax_v(const uint16_t* in, uint16_t* out,
+                                                    int rows, int cols, int pitch, int w)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= pitch)
+        return;
+    uint16_t m = 0;
+    if (c < cols) {
+        const int r0 = min(r, rows - w);
+        for (int k = 0; k < w; ++k)
+            m = max(m, in[(size_t)(r0 + k) * pitch + c]);
+    }
+    out[(size_t)r * pitch + c] = m;
+}
+
+/* out[r][c] = max_{k<w} in[r][min(c, cols-w)+k] */
+__global__ __launch_bounds__(kBlock) void k_boxmax_h(const uint16_t* in, uint16_t* out,
+                                                    int rows, int cols, int pitch, int w)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= pitch)
+        return;
+    uint16_t m = 0;
+    if (c < cols) {
+        const int c0 = min(c, cols - w);
+        const uint16_t* p = in + (size_t)r * pitch + c0;
+        for (int k = 0; k < w; ++k)
+            m = max(m, p[k]);
+    }
+    out[(size_t)r * pitch + c] = m;
+}
+
+/* ------------------------------------------------------------------ K4 */
+__global__ __launch_bounds__(kBlock) void k_finalize(FinalJob job)
+{
+    extern __shared__ double sm_p[];            /* [n_points] probabilities */
+    __shared__ unsigned long long red_key[kBlock];
+    __shared__ unsigned long long red_rank[kBlock];
+    __shared__ uint32_t red_cnt[kBlock];
+    __shared__ uint32_t red_s[kBlock], red_k[kBlock];
+    const int tid = threadIdx.x;
+
+    unsigned long long bkey = 0, brank = ~0ull;
+    uint32_t bcnt = 0;
+    for (int i = tid; i < job.n_entries; i += kBlock) {
+        const BlockBest bb = job.block_best[i];
+        best_combine(bkey, brank, bcnt, bb.key, bb.rank, bb.count);
+    }
+    red_key[tid] = bkey;
+    red_rank[tid] = brank;
+    red_cnt[tid] = bcnt;
+    __syncthreads();
+    for (int s = kBlock / 2; s >= 1; s >>= 1) {
+        if (tid < s) {
+            best_combine(bkey, brank, bcnt, red_key[tid + s], red_rank[tid + s], red_cnt[tid + s]);
+            red_key[tid] = bkey;
+            red_rank[tid] = brank;
+            red_cnt[tid] = bcnt;
+        }
+        __syncthreads();
+    }
+    bkey = red_key[0];
+    brank = red_rank[0];
+    bcnt = red_cnt[0];
+
+    csm_result* out = reinterpret_cast<csm_result*>(job.out);
+    const uint32_t flags_in = job.flags_in ? (*job.flags_in & 0xffffu) : 0u;
+    if (bkey == 0) {
+        if (tid == 0) {
+            csm_result r;
+            r.found = 0;
+            r.best_x = job.init_x;
+            r.best_y = job.init_y;
+            r.best_theta = job.init_theta;
+            r.key = 0;
+            r.sum_values = 0;
+            r.known = 0;
+            r.tie_count = 0;
+            r.flags = flags_in;
+            r.score = job.score_thr;
+            *out = r;
+        }
+        return;
+    }
+    /* decode the traversal rank */
+    const int L = job.rank_l;
+    const int nxc = job.nx / L, nyc = job.ny / L;
+    unsigned long long q = brank;
+    const int fy = (int)(q % L); q /= L;
+    const int fx = (int)(q % L); q /= L;
+    const int yc = (int)(q % nyc); q /= nyc;
+    const int xc = (int)(q % nxc); q /= nxc;
+    const int t = (int)q;
+    const int x = job.x_lo + xc * L + fx, y = job.y_lo + yc * L + fy;
+
+    /* f64 replay of the winner: gather in parallel, sum in beam order */
+    const int32_t* col = job.hit_col + (size_t)t * job.n_points;
+    const int32_t* row = job.hit_row + (size_t)t * job.n_points;
+    uint32_t s = 0, k = 0;
+    for (int i = tid; i < job.n_points; i += kBlock) {
+        const int r = row[i] + y, c = col[i] + x;
+        uint32_t v = 0;
+        if (r >= 0 && r < job.rows && c >= 0 && c < job.cols)
+            v = job.cells[(size_t)r * job.pitch + c];
+        sm_p[i] = job.lut[v];
+        s += v;
+        k += v != 0;
+    }
+    red_s[tid] = s;
+    red_k[tid] = k;
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < job.n_points; ++i) {
+            const double p = sm_p[i];
+            if (p != 0.0)
+                sum += p;
+        }
+        uint32_t st = 0, kt = 0;
+        for (int i = 0; i < kBlock; ++i) {
+            st += red_s[i];
+            kt += red_k[i];
+        }
+        const double score = sum / (double)job.n_points;
+        csm_result r;
+        r.found = score > job.score_thr ? 1 : 0;
+        r.best_x = x;
+        r.best_y = y;
+        r.best_theta = t - job.win_theta;
+        r.key = bkey;
+        r.sum_values = st;
+        r.known = kt;
+        r.tie_count = bcnt;
+        r.flags = flags_in | (bcnt > 1 ? CSM_FLAG_KEY_TIE : 0u);
+        r.score = r.found ? score : job.score_thr;
+        if (!r.found) {
+            r.best_x = job.init_x;
+            r.best_y = job.init_y;
+            r.best_theta = job.init_theta;
+        }
+        *out = r;
+    }
+}
+
+} /* namespace csm */

@@ -1,0 +1,223 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes wrapper of oracle/_build/libcsm_oracle.so
+(the CPU restatement in oracle/csm_oracle.cpp) and, where it was built, of
+oracle/_ref/libref_geom.so (the reference's own header-only geometry).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module. The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "_build", "libcsm_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libref_geom.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+class CsmParams(C.Structure):
+    _fields_ = [("rangeX", C.c_double), ("rangeY", C.c_double), ("rangeT", C.c_double),
+                ("lowRes", C.c_int), ("scoreThr", C.c_double), ("knownThr", C.c_double)]
+
+
+class BnbParams(C.Structure):
+    _fields_ = [("rangeX", C.c_double), ("rangeY", C.c_double), ("rangeT", C.c_double),
+                ("nodeHeightMax", C.c_int), ("scoreThr", C.c_double), ("knownThr", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("found", C.c_int), ("bestX", C.c_int), ("bestY", C.c_int), ("bestT", C.c_int),
+                ("winX", C.c_int), ("winY", C.c_int), ("winT", C.c_int),
+                ("stepX", C.c_double), ("stepY", C.c_double), ("stepT", C.c_double),
+                ("scoreMax", C.c_double), ("sensorPose", C.c_double * 3),
+                ("bestSensorPose", C.c_double * 3), ("estimatedPose", C.c_double * 3),
+                ("ignoredNodes", C.c_longlong), ("processedNodes", C.c_longlong),
+                ("fineEvaluated", C.c_longlong)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        _lib = C.CDLL(ORACLE_SO)
+        _lib.orc_value_to_probability.restype = C.c_double
+        _lib.orc_value_to_probability.argtypes = [C.c_uint]
+        _lib.orc_score_at.restype = C.c_double
+    return _lib
+
+
+def ref():
+    """The reference-built geometry library, or None when absent (GPU box)."""
+    global _ref
+    if _ref is None and os.path.exists(REF_SO):
+        _ref = C.CDLL(REF_SO)
+        _ref.ref_value_to_probability.restype = C.c_double
+        _ref.ref_value_to_probability.argtypes = [C.c_uint]
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def compound(a, b):
+    out = np.zeros(3)
+    lib().orc_compound(_p(_f64(a)), _p(_f64(b)), _p(out))
+    return out
+
+
+def inverse_compound(a, b):
+    out = np.zeros(3)
+    lib().orc_inverse_compound(_p(_f64(a)), _p(_f64(b)), _p(out))
+    return out
+
+
+def move_backward(a, b):
+    out = np.zeros(3)
+    lib().orc_move_backward(_p(_f64(a)), _p(_f64(b)), _p(out))
+    return out
+
+
+def lut():
+    t = np.zeros(65536)
+    lib().orc_lut(_p(t))
+    return t
+
+
+def boxmax(grid, win):
+    g = np.ascontiguousarray(grid, dtype=np.uint16)
+    out = np.zeros_like(g)
+    rc = lib().orc_boxmax(_p(g), g.shape[0], g.shape[1], win, _p(out))
+    if rc:
+        raise ValueError("window does not fit")
+    return out
+
+
+def search_step(res, ranges):
+    r = _f64(ranges)
+    sx, sy, st = C.c_double(), C.c_double(), C.c_double()
+    lib().orc_search_step(C.c_double(res), _p(r), r.size, C.byref(sx), C.byref(sy), C.byref(st))
+    return sx.value, sy.value, st.value
+
+
+def project(geom, pose, angles, ranges):
+    a, r = _f64(angles), _f64(ranges)
+    col = np.zeros(a.size, np.int32)
+    row = np.zeros(a.size, np.int32)
+    lib().orc_project(_p(_f64(geom)), _p(_f64(pose)), _p(a), _p(r), a.size, _p(col), _p(row))
+    return col, row
+
+
+def _csm_args(case, coarse):
+    g = np.ascontiguousarray(case["grid"], dtype=np.uint16)
+    c = np.ascontiguousarray(coarse, dtype=np.uint16)
+    a, r = _f64(case["angles"]), _f64(case["ranges"])
+    return g, c, a, r, _f64(case["geom"]), _f64(case["rel_pose"]), _f64(case["init_pose"])
+
+
+def csm(case, range_x, range_y, range_t, low_res, score_thr=0.0, known_thr=0.0, coarse=None):
+    """Literal ScanMatcherCorrelative::OptimizePose (sequential sweep + pruning)."""
+    if coarse is None:
+        coarse = boxmax(case["grid"], low_res)
+    g, c, a, r, geom, rel, init = _csm_args(case, coarse)
+    p = CsmParams(range_x, range_y, range_t, low_res, score_thr, known_thr)
+    out = Result()
+    lib().orc_csm(_p(g), _p(c), g.shape[0], g.shape[1], _p(geom), _p(a), _p(r), a.size,
+                  _p(rel), _p(init), C.byref(p), C.byref(out))
+    return out.as_dict()
+
+
+def csm_closed_form(case, range_x, range_y, range_t, low_res, score_thr=0.0, known_thr=0.0,
+                    coarse=None, dump=False):
+    if coarse is None:
+        coarse = boxmax(case["grid"], low_res)
+    g, c, a, r, geom, rel, init = _csm_args(case, coarse)
+    p = CsmParams(range_x, range_y, range_t, low_res, score_thr, known_thr)
+    out = Result()
+    band = C.c_int(0)
+    S = K = CK = None
+    if dump:
+        sx, sy, st = search_step(geom[0], r)
+        import math
+        wx = int(math.ceil(0.5 * range_x / sx))
+        wy = int(math.ceil(0.5 * range_y / sy))
+        wt = int(math.ceil(0.5 * range_t / st))
+        nxc, nyc = -(-(2 * wx + 1) // low_res), -(-(2 * wy + 1) // low_res)
+        S = np.zeros((2 * wt + 1, nxc * low_res, nyc * low_res), np.uint32)
+        K = np.zeros((2 * wt + 1, nxc * low_res, nyc * low_res), np.uint16)
+        CK = np.zeros((2 * wt + 1, nxc, nyc), np.uint16)
+    lib().orc_csm_closed_form(_p(g), _p(c), g.shape[0], g.shape[1], _p(geom), _p(a), _p(r),
+                              a.size, _p(rel), _p(init), C.byref(p), C.byref(out),
+                              C.byref(band), _p(S) if dump else None, _p(K) if dump else None,
+                              _p(CK) if dump else None)
+    d = out.as_dict()
+    d["touchesBand"] = band.value
+    return (d, S, K, CK) if dump else d
+
+
+def pyramid(grid, node_height_max):
+    return np.stack([boxmax(grid, 1 << h) for h in range(node_height_max + 1)])
+
+
+def bnb(case, range_x, range_y, range_t, node_height_max, score_thr, known_thr, pyr=None):
+    """Literal ScanMatcherBranchBound::OptimizePose (std::priority_queue)."""
+    if pyr is None:
+        pyr = pyramid(case["grid"], node_height_max)
+    pyr = np.ascontiguousarray(pyr, dtype=np.uint16)
+    a, r = _f64(case["angles"]), _f64(case["ranges"])
+    geom, rel, init = _f64(case["geom"]), _f64(case["rel_pose"]), _f64(case["init_pose"])
+    p = BnbParams(range_x, range_y, range_t, node_height_max, score_thr, known_thr)
+    out = Result()
+    lib().orc_bnb(_p(pyr), pyr.shape[1], pyr.shape[2], _p(geom), _p(a), _p(r), a.size,
+                  _p(rel), _p(init), C.byref(p), C.byref(out))
+    return out.as_dict()
+
+
+def bnb_level_dump(case, level_grid, h, range_x, range_y, range_t, node_height_max):
+    import math
+    lv = np.ascontiguousarray(level_grid, dtype=np.uint16)
+    a, r = _f64(case["angles"]), _f64(case["ranges"])
+    geom, rel, init = _f64(case["geom"]), _f64(case["rel_pose"]), _f64(case["init_pose"])
+    p = BnbParams(range_x, range_y, range_t, node_height_max, 0.0, 0.0)
+    sx, sy, st = search_step(geom[0], r)
+    wx = int(math.ceil(0.5 * range_x / sx))
+    wy = int(math.ceil(0.5 * range_y / sy))
+    wt = int(math.ceil(0.5 * range_t / st))
+    big, s = 1 << node_height_max, 1 << h
+    nx = -(-(2 * wx + 1) // big) * big // s
+    ny = -(-(2 * wy + 1) // big) * big // s
+    S = np.zeros((2 * wt + 1, nx, ny), np.uint32)
+    K = np.zeros((2 * wt + 1, nx, ny), np.uint16)
+    lib().orc_bnb_level_dump(_p(lv), lv.shape[0], lv.shape[1], _p(geom), _p(a), _p(r), a.size,
+                             _p(rel), _p(init), C.byref(p), h, _p(S), _p(K))
+    return S, K
+
+
+def score_at(level_grid, geom, angles, ranges, pose):
+    lv = np.ascontiguousarray(level_grid, dtype=np.uint16)
+    a, r = _f64(angles), _f64(ranges)
+    known = C.c_int(0)
+    s = lib().orc_score_at(_p(lv), lv.shape[0], lv.shape[1], _p(_f64(geom)), _p(a), _p(r),
+                           a.size, _p(_f64(pose)), C.byref(known))
+    return s, known.value

@@ -1,0 +1,67 @@
+"""GPU parity: the HIP correlative path, through the C ABI, against the CPU
+oracle on the same seeded inputs. Bar: integer sums and best-pose indices
+bit-exact; the f64 score bit-exact too (tolerance 0: it is replayed in beam
+order in f64 on the device)."""
+import math
+
+import numpy as np
+import pytest
+
+from csm_hip import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _window_for(case, rx, ry, rt, L, score_thr=0.0, known_thr=0.0):
+    res = case["geom"][0]
+    sx, sy, st = api.host_search_step(res, case["ranges"])
+    wx, wy, wt = api.host_window(rx, sx), api.host_window(ry, sy), api.host_window(rt, st)
+    sensor = api.host_compound(case["init_pose"], case["rel_pose"])
+    col, row = api.host_project(case["geom"], sensor, st, wt, case["angles"], case["ranges"])
+    n = len(case["angles"])
+    return (wx, wy, wt), col, row, api.host_min_known(n, known_thr)
+
+
+@pytest.mark.parametrize("win", [1, 2, 3, 4, 5, 8, 16, 64])
+def test_boxmax_matches_oracle(gpu_ctx, oracle, win):
+    grid, _, _ = synth.make_room(3, rows=208, cols=176)
+    gpu_ctx.upload_grid(100, grid)
+    gpu_ctx.build_pyramid(100, [1, win])
+    got = gpu_ctx.download_level(100, 1)
+    assert np.array_equal(gpu_ctx.download_level(100, 0), grid)
+    assert np.array_equal(got, oracle.boxmax(grid, win))
+    gpu_ctx.release_grid(100)
+
+
+@pytest.mark.parametrize("seed,L", [(0, 4), (1, 4), (2, 1), (3, 5), (4, 3), (5, 8)])
+def test_config1_all_candidates_and_winner(gpu_ctx, oracle, seed, L):
+    case = synth.csm_case(seed)
+    rx, ry, rt = 1.0, 1.0, math.radians(10)
+    (wx, wy, wt), col, row, mk = _window_for(case, rx, ry, rt, L)
+    gpu_ctx.upload_grid(1, case["grid"])
+    gpu_ctx.build_pyramid(1, [1, L])
+    w = gpu_ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, L, 1, mk, 0.0)
+    res, S, K, CK = gpu_ctx.score_window(1, w, col, row, dump=True)
+    want, oS, oK, oCK = oracle.csm_closed_form(case, rx, ry, rt, L, dump=True)
+    lit = oracle.csm(case, rx, ry, rt, L)
+    assert np.array_equal(S, oS)
+    assert np.array_equal(K, oK)
+    if L > 1:
+        assert np.array_equal(CK, oCK)
+    assert (res["best_x"], res["best_y"], res["best_theta"]) == (lit["bestX"], lit["bestY"], lit["bestT"])
+    assert res["found"] == lit["found"]
+    assert res["score"] == lit["scoreMax"]          # bit-exact f64
+    assert want["scoreMax"] == lit["scoreMax"]
+    gpu_ctx.release_grid(1)
+
+
+def test_config1_match_summary(gpu_ctx, oracle):
+    case = synth.csm_case(11, rel_pose=(0.12, -0.03, 0.05))
+    m = api.ScanMatcherCorrelativeHIP("csm", 4, 1.0, 1.0, math.radians(10), ctx=gpu_ctx)
+    out = m.optimize_pose(case["grid"], case["geom"], case["angles"], case["ranges"],
+                          case["rel_pose"], case["init_pose"])
+    lit = oracle.csm(case, 1.0, 1.0, math.radians(10), 4)
+    assert out["pose_found"] == lit["found"] == 1
+    assert (out["win_x"], out["win_y"], out["win_theta"]) == (lit["winX"], lit["winY"], lit["winT"])
+    assert out["estimated_pose"] == lit["estimatedPose"]      # bit-exact doubles
+    assert out["raw"]["score"] == lit["scoreMax"]
