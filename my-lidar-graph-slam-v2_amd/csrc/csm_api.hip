@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "csm_kernels.hip"
@@ -62,6 +63,7 @@ struct csm_ctx {
     double* lut_dev = nullptr;
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
+    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     bool timing = false;
     std::map<std::string, KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -169,6 +171,7 @@ struct Plan {
 };
 
 const int kRChoices[] = { 4, 5, 6, 7, 8 };
+const int kCoarseSlices = 8;
 
 void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* R,
                  int* ncbx, int* ncby, bool fixed_r1)
@@ -275,9 +278,9 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
     }
 
 int launch_score(csm_ctx* ctx, const ScoreJob& job, int lstride, int R, bool strided,
-                 int cbx, int groups, int ncb, int n_theta)
+                 int cbx, int groups, int ncb, int n_theta, int n_slices)
 {
-    const dim3 grid(ncb, n_theta, 1);
+    const dim3 grid(ncb, n_theta, n_slices);
     const int stride = strided ? job.stride : 1;
     const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 2;
     if (lds > 160 * 1024 - 256)
@@ -386,7 +389,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     if ((rc = ensure(ctx, ctx->ntiles, nt * 4))) return rc;
     if ((rc = ensure(ctx, ctx->misc, 256))) return rc;
     if ((rc = ensure(ctx, ctx->coarse_s, nt * p.nxc * p.nyc * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->coarse_k, nt * p.nxc * p.nyc * 2))) return rc;
+    if ((rc = ensure(ctx, ctx->coarse_k, nt * p.nxc * p.nyc * 4))) return rc;
     const int ncb = p.ncbx * p.ncby;
     if ((rc = ensure(ctx, ctx->best, nt * ncb * sizeof(BlockBest)))) return rc;
 
@@ -449,12 +452,17 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         cj.nx = p.nxc;
         cj.ny = p.nyc;
         cj.stride = p.L;
-        cj.dump_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
-        cj.dump_k = reinterpret_cast<uint16_t*>(ctx->coarse_k.p);
+        cj.acc_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
+        cj.acc_k = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
         cj.rank_l = 1;
+        const size_t nodes = nt * p.nxc * p.nyc;
         ScopedTimer tm(ctx, "score_coarse");
+        HIP_TRY(ctx, hipMemsetAsync(cj.acc_s, 0, nodes * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(cj.acc_k, 0, nodes * 4, ctx->stream));
+        /* few candidates per slice: split the tile list over blockIdx.z so
+         * enough workgroups are in flight to hide the staging latency */
         if ((rc = launch_score(ctx, cj, p.lstride, 1, true, p.c_cbx, p.c_groups,
-                               p.c_ncbx * p.c_ncby, p.n_theta)))
+                               p.c_ncbx * p.c_ncby, p.n_theta, kCoarseSlices)))
             return rc;
     }
 
@@ -471,7 +479,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     }
     if (p.L > 1) {
         fj.n_elig = 1;
-        fj.elig[0].k = reinterpret_cast<const uint16_t*>(ctx->coarse_k.p);
+        fj.elig[0].k = reinterpret_cast<const uint32_t*>(ctx->coarse_k.p);
         fj.elig[0].s = reinterpret_cast<const uint32_t*>(ctx->coarse_s.p);
         fj.elig[0].div = p.L;
         fj.elig[0].nxc = p.nxc;
@@ -481,7 +489,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     }
     {
         ScopedTimer tm(ctx, "score_fine");
-        if ((rc = launch_score(ctx, fj, p.lstride, p.R, false, p.cbx, p.groups, ncb, p.n_theta)))
+        if ((rc = launch_score(ctx, fj, p.lstride, p.R, false, p.cbx, p.groups, ncb, p.n_theta, 1)))
             return rc;
     }
 
@@ -567,7 +575,8 @@ int csm_destroy(csm_ctx* ctx)
         free_levels(kv.second, false);
     DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
-                       &ctx->scratch };
+                       &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
+                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out };
     for (DevBuf* b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -862,10 +871,15 @@ int csm_score_window_dump(csm_ctx* ctx, uint64_t map_id, const csm_window* w, co
         HIP_TRY(ctx, hipMemcpyAsync(dump_s, dumps.dump_s, nc * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (dump_k)
         HIP_TRY(ctx, hipMemcpyAsync(dump_k, dumps.dump_k, nc * 2, hipMemcpyDeviceToHost, ctx->stream));
-    if (dump_coarse_k && p.L > 1)
-        HIP_TRY(ctx, hipMemcpyAsync(dump_coarse_k, ctx->coarse_k.p, (size_t)p.n_theta * p.nxc * p.nyc * 2,
+    std::vector<uint32_t> ck32;
+    if (dump_coarse_k && p.L > 1) {
+        ck32.resize((size_t)p.n_theta * p.nxc * p.nyc);
+        HIP_TRY(ctx, hipMemcpyAsync(ck32.data(), ctx->coarse_k.p, ck32.size() * 4,
                                     hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ck32.size(); ++i)
+        dump_coarse_k[i] = (uint16_t)ck32[i];
     return CSM_OK;
 }
 
@@ -939,14 +953,470 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     return CSM_OK;
 }
 
-int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_queries,
-                        const csm_bnb_params* params, csm_summary* out)
+} /* extern "C" */
+
+/* ---- branch-and-bound batch ---- */
+
+namespace {
+
+#define LAUNCH_SCORE_B(LS, RR, ST)                                                    \
+    do {                                                                              \
+        int rc_ = set_lds(ctx, k_score_batch<LS, RR, ST>, lds);                       \
+        if (rc_)                                                                      \
+            return rc_;                                                               \
+        hipLaunchKernelGGL((k_score_batch<LS, RR, ST>), grid, dim3(kBlock), lds,      \
+                           ctx->stream, jobs_dev, cbx, groups, n_slices);             \
+    } while (0)
+
+#define DISPATCH_R_B(LS)                                                              \
+    switch (R) {                                                                      \
+    case 4: LAUNCH_SCORE_B(LS, 4, false); break;                                      \
+    case 5: LAUNCH_SCORE_B(LS, 5, false); break;                                      \
+    case 6: LAUNCH_SCORE_B(LS, 6, false); break;                                      \
+    case 7: LAUNCH_SCORE_B(LS, 7, false); break;                                      \
+    case 8: LAUNCH_SCORE_B(LS, 8, false); break;                                      \
+    default: return fail(ctx, CSM_EINVAL, "internal: R");                             \
+    }
+
+int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, int lstride, int R,
+                       bool strided, int stride, int cbx, int groups, int ncb, int n_theta_max,
+                       int n_slices)
 {
-    (void)queries;
-    (void)n_queries;
-    (void)params;
-    (void)out;
-    return fail(ctx, CSM_EINVAL, "csm_bnb_match_batch: not built yet");
+    const dim3 grid(ncb, n_theta_max, n_jobs * n_slices);
+    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 2;
+    if (lds > 160 * 1024 - 256)
+        return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
+    if (strided) {
+        switch (lstride) {
+        case 64: LAUNCH_SCORE_B(64, 1, true); break;
+        case 96: LAUNCH_SCORE_B(96, 1, true); break;
+        case 128: LAUNCH_SCORE_B(128, 1, true); break;
+        case 160: LAUNCH_SCORE_B(160, 1, true); break;
+        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
+        }
+    } else {
+        switch (lstride) {
+        case 64: DISPATCH_R_B(64); break;
+        case 96: DISPATCH_R_B(96); break;
+        case 128: DISPATCH_R_B(128); break;
+        case 160: DISPATCH_R_B(160); break;
+        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
+struct BnbPrep {
+    DeviceGrid* grid = nullptr;
+    int level[kMaxElig] = { 0 };   /* index into grid->levels of box-max(2^h) */
+    int n_theta = 0, n = 0;
+    int win_x = 0, win_y = 0, win_t = 0;
+    int nx = 0, ny = 0;
+    int tiles_x = 0, tiles_y = 0, max_tiles = 0;
+    size_t hit_off = 0, tile_off = 0, theta_off = 0, best_off = 0;
+    size_t lvl_off[kMaxElig] = { 0 };
+};
+
+/* One group of queries that share (nx, ny): the whole device pipeline. */
+int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector<int>& idx,
+                  const std::vector<std::vector<int>>& levels, const csm_bnb_params* prm,
+                  csm_summary* out)
+{
+    const int H = prm->node_height_max;
+    const int nq = (int)idx.size();
+    std::vector<BnbPrep> pp(nq);
+    int rc;
+
+    /* ---- host set-up: window, projection products (threaded over queries) ---- */
+    size_t hit_total = 0, tile_total = 0, theta_total = 0;
+    int n_theta_max = 0, n_points_max = 0;
+    size_t bin_lds = 0;
+    for (int k = 0; k < nq; ++k) {
+        const csm_loop_query& q = queries[idx[k]];
+        csm_summary& o = out[idx[k]];
+        BnbPrep& p = pp[k];
+        p.grid = find_grid(ctx, q.map_id);
+        for (int h = 0; h <= H; ++h)
+            p.level[h] = levels[idx[k]][h];
+        csm_host_compound(q.initial_pose, q.scan.relative_sensor_pose, o.sensor_pose);
+        csm_host_search_step(q.geometry.resolution, q.scan.ranges, q.scan.n_points, &o.step_x,
+                             &o.step_y, &o.step_theta);
+        o.win_x = p.win_x = csm_host_window(prm->range_x, o.step_x);
+        o.win_y = p.win_y = csm_host_window(prm->range_y, o.step_y);
+        o.win_theta = p.win_t = csm_host_window(prm->range_theta, o.step_theta);
+        p.n_theta = 2 * p.win_t + 1;
+        p.n = q.scan.n_points;
+        const int big = 1 << H;
+        p.nx = ceil_div(2 * p.win_x + 1, big) * big;
+        p.ny = ceil_div(2 * p.win_y + 1, big) * big;
+        p.tiles_x = ceil_div(p.grid->cols + p.win_x + (-p.win_x + p.nx - 1), kTile);
+        p.tiles_y = ceil_div(p.grid->rows + p.win_y + (-p.win_y + p.ny - 1), kTile);
+        p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y);
+        bin_lds = std::max(bin_lds, (2 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4);
+        p.hit_off = hit_total;
+        p.tile_off = tile_total;
+        p.theta_off = theta_total;
+        hit_total += (size_t)p.n_theta * p.n;
+        tile_total += (size_t)p.n_theta * p.max_tiles;
+        theta_total += p.n_theta;
+        n_theta_max = std::max(n_theta_max, p.n_theta);
+        n_points_max = std::max(n_points_max, p.n);
+    }
+    if (bin_lds > 160 * 1024)
+        return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
+    const int nx = pp[0].nx, ny = pp[0].ny;
+
+    std::vector<double> prod(hit_total * 2);
+    double* h_rc = prod.data();
+    double* h_rs = prod.data() + hit_total;
+    {
+        unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        nthreads = std::min<unsigned>(nthreads, nq);
+        std::vector<std::thread> pool;
+        std::vector<int> status(nq, 0);
+        for (unsigned w = 0; w < nthreads; ++w)
+            pool.emplace_back([&, w]() {
+                std::vector<int32_t> col, row;
+                for (int k = w; k < nq; k += nthreads) {
+                    const csm_loop_query& q = queries[idx[k]];
+                    const BnbPrep& p = pp[k];
+                    col.resize((size_t)p.n_theta * p.n);
+                    row.resize((size_t)p.n_theta * p.n);
+                    status[k] = csm_host_project(&q.geometry, out[idx[k]].sensor_pose,
+                                                 out[idx[k]].step_theta, p.win_t, q.scan.angles,
+                                                 q.scan.ranges, p.n, col.data(), row.data(),
+                                                 h_rc + p.hit_off, h_rs + p.hit_off);
+                }
+            });
+        for (auto& t : pool)
+            t.join();
+        for (int k = 0; k < nq; ++k)
+            if (status[k])
+                return fail(ctx, status[k], "projection failed for query %d", idx[k]);
+    }
+
+    /* ---- launch geometry shared by the group ---- */
+    int cbx, groups, R, ncbx, ncby;
+    plan_blocks(nx, ny, 1, &cbx, &groups, &R, &ncbx, &ncby, false);
+    const int need = kTile + 7 + cbx;
+    if (need > 160)
+        return fail(ctx, CSM_EINVAL, "internal: candidate block too wide");
+    const int lstride = need <= 64 ? 64 : need <= 96 ? 96 : need <= 128 ? 128 : 160;
+    const int ncb = ncbx * ncby;
+
+    /* ---- workspaces ---- */
+    size_t lvl_total = 0, best_total = 0;
+    for (int k = 0; k < nq; ++k) {
+        BnbPrep& p = pp[k];
+        for (int h = 1; h <= H; ++h) {
+            p.lvl_off[h] = lvl_total;
+            lvl_total += (size_t)p.n_theta * (nx >> h) * (ny >> h);
+        }
+        p.best_off = best_total;
+        best_total += (size_t)p.n_theta * ncb;
+    }
+    if ((rc = ensure(ctx, ctx->b_prod, hit_total * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->b_hits, hit_total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->b_sorted, hit_total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->b_tiles, tile_total * sizeof(TileRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_ntiles, theta_total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->b_lvl, lvl_total * 8 + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->b_best, best_total * sizeof(BlockBest)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_out, (size_t)nq * (sizeof(csm_result) + 4)))) return rc;
+    const size_t jobs_bytes = (size_t)nq * (sizeof(IndexJob) + sizeof(BinJob) + sizeof(FinalJob) +
+                                            (size_t)(H + 1) * sizeof(ScoreJob));
+    if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + 1024))) return rc;
+
+    double* d_rc = reinterpret_cast<double*>(ctx->b_prod.p);
+    double* d_rs = d_rc + hit_total;
+    int32_t* d_col = reinterpret_cast<int32_t*>(ctx->b_hits.p);
+    int32_t* d_row = d_col + hit_total;
+    uint32_t* d_sorted = reinterpret_cast<uint32_t*>(ctx->b_sorted.p);
+    TileRec* d_tiles = reinterpret_cast<TileRec*>(ctx->b_tiles.p);
+    int32_t* d_ntiles = reinterpret_cast<int32_t*>(ctx->b_ntiles.p);
+    uint32_t* d_lvl_s = reinterpret_cast<uint32_t*>(ctx->b_lvl.p);
+    uint32_t* d_lvl_k = d_lvl_s + lvl_total;
+    BlockBest* d_best = reinterpret_cast<BlockBest*>(ctx->b_best.p);
+    csm_result* d_out = reinterpret_cast<csm_result*>(ctx->b_out.p);
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_out + nq);
+
+    HIP_TRY(ctx, hipMemcpyAsync(d_rc, prod.data(), hit_total * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, (size_t)nq * 4, ctx->stream));
+    if (lvl_total)
+        HIP_TRY(ctx, hipMemsetAsync(d_lvl_s, 0, lvl_total * 8, ctx->stream));
+
+    /* ---- job tables ---- */
+    std::vector<IndexJob> ij(nq);
+    std::vector<BinJob> bj(nq);
+    std::vector<FinalJob> fj(nq);
+    std::vector<std::vector<ScoreJob>> sj(H + 1, std::vector<ScoreJob>(nq));
+    for (int k = 0; k < nq; ++k) {
+        const csm_loop_query& q = queries[idx[k]];
+        const csm_summary& o = out[idx[k]];
+        const BnbPrep& p = pp[k];
+        const DeviceGrid& g = *p.grid;
+        const int x_lo = -p.win_x, y_lo = -p.win_y;
+        const int min_known = csm_host_min_known(p.n, prm->known_rate_threshold);
+
+        IndexJob& I = ij[k];
+        std::memset(&I, 0, sizeof(I));
+        I.r_cos = d_rc + p.hit_off;
+        I.r_sin = d_rs + p.hit_off;
+        I.hit_col = d_col + p.hit_off;
+        I.hit_row = d_row + p.hit_off;
+        I.flags = d_flags + k;
+        I.n_theta = p.n_theta;
+        I.n_points = p.n;
+        I.x_lo = x_lo;
+        I.y_lo = y_lo;
+        I.nx = nx;
+        I.ny = ny;
+        I.sensor_x = o.sensor_pose[0];
+        I.sensor_y = o.sensor_pose[1];
+        I.step_x = o.step_x;
+        I.step_y = o.step_y;
+        I.off_x = q.geometry.offset_x;
+        I.off_y = q.geometry.offset_y;
+        I.res = q.geometry.resolution;
+
+        BinJob& B = bj[k];
+        std::memset(&B, 0, sizeof(B));
+        B.hit_col = I.hit_col;
+        B.hit_row = I.hit_row;
+        B.sorted_pb = d_sorted + p.hit_off;
+        B.tiles = d_tiles + p.tile_off;
+        B.n_tiles = d_ntiles + p.theta_off;
+        B.flags = d_flags + k;
+        B.n_theta = p.n_theta;
+        B.n_points = p.n;
+        B.max_tiles = p.max_tiles;
+        B.rows = g.rows;
+        B.cols = g.cols;
+        B.x_lo = x_lo;
+        B.y_lo = y_lo;
+        B.x_hi = x_lo + nx - 1;
+        B.y_hi = y_lo + ny - 1;
+        B.tiles_x = p.tiles_x;
+        B.tiles_y = p.tiles_y;
+        B.lstride = lstride;
+        B.n_band = H;
+        for (int h = 1; h <= H; ++h) {
+            B.band_win[h - 1] = 1 << h;
+            B.band_nx[h - 1] = nx >> h;
+            B.band_ny[h - 1] = ny >> h;
+        }
+
+        ScoreJob base;
+        std::memset(&base, 0, sizeof(base));
+        base.rows = g.rows;
+        base.cols = g.cols;
+        base.pitch = g.pitch;
+        base.sorted_pb = B.sorted_pb;
+        base.tiles = B.tiles;
+        base.n_tiles = B.n_tiles;
+        base.n_theta = p.n_theta;
+        base.n_points = p.n;
+        base.max_tiles = p.max_tiles;
+        base.x_lo = x_lo;
+        base.y_lo = y_lo;
+        base.flags = d_flags + k;
+        base.min_known = min_known;
+        base.rank_l = 1;
+        for (int h = 1; h <= H; ++h) {
+            ScoreJob& S = sj[h][k];
+            S = base;
+            S.cells = g.levels[p.level[h]].cells;
+            S.nx = nx >> h;
+            S.ny = ny >> h;
+            S.stride = 1 << h;
+            S.acc_s = d_lvl_s + p.lvl_off[h];
+            S.acc_k = d_lvl_k + p.lvl_off[h];
+        }
+        ScoreJob& F = sj[0][k];
+        F = base;
+        F.cells = g.levels[p.level[0]].cells;
+        F.nx = nx;
+        F.ny = ny;
+        F.stride = 1;
+        F.block_best = d_best + p.best_off;
+        F.check_own_known = 1;
+        F.n_elig = H;
+        for (int h = 1; h <= H; ++h) {
+            F.elig[h - 1].k = d_lvl_k + p.lvl_off[h];
+            F.elig[h - 1].s = d_lvl_s + p.lvl_off[h];
+            F.elig[h - 1].div = 1 << h;
+            F.elig[h - 1].nxc = nx >> h;
+            F.elig[h - 1].nyc = ny >> h;
+        }
+
+        FinalJob& Z = fj[k];
+        std::memset(&Z, 0, sizeof(Z));
+        Z.block_best = F.block_best;
+        Z.n_entries = p.n_theta * ncb;
+        Z.nx = nx;
+        Z.ny = ny;
+        Z.rank_l = 1;
+        Z.x_lo = x_lo;
+        Z.y_lo = y_lo;
+        Z.win_theta = p.win_t;
+        Z.init_x = 0;     /* scan_matcher_branch_bound.cpp:144-146 */
+        Z.init_y = 0;
+        Z.init_theta = 0;
+        Z.cells = F.cells;
+        Z.rows = g.rows;
+        Z.cols = g.cols;
+        Z.pitch = g.pitch;
+        Z.hit_col = I.hit_col;
+        Z.hit_row = I.hit_row;
+        Z.n_points = p.n;
+        Z.score_thr = prm->score_threshold;
+        Z.lut = ctx->lut_dev;
+        Z.flags_in = d_flags + k;
+        Z.out = d_out + k;
+    }
+    /* upload the job tables (one buffer, 16-byte aligned sections) */
+    char* jb = reinterpret_cast<char*>(ctx->b_jobs.p);
+    auto put = [&](const void* src, size_t bytes, char** dev) -> hipError_t {
+        *dev = jb;
+        jb += (bytes + 255) & ~(size_t)255;
+        return hipMemcpyAsync(*dev, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    };
+    /* sections were sized without the 256-byte rounding: grow if needed */
+    if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + 256 * (size_t)(H + 8)))) return rc;
+    jb = reinterpret_cast<char*>(ctx->b_jobs.p);
+    char *d_ij, *d_bj, *d_fj;
+    std::vector<char*> d_sj(H + 1);
+    HIP_TRY(ctx, put(ij.data(), nq * sizeof(IndexJob), &d_ij));
+    HIP_TRY(ctx, put(bj.data(), nq * sizeof(BinJob), &d_bj));
+    HIP_TRY(ctx, put(fj.data(), nq * sizeof(FinalJob), &d_fj));
+    for (int h = 0; h <= H; ++h)
+        HIP_TRY(ctx, put(sj[h].data(), nq * sizeof(ScoreJob), &d_sj[h]));
+
+    /* ---- launches ---- */
+    {
+        ScopedTimer tm(ctx, "bnb_index");
+        hipLaunchKernelGGL(k_bnb_index, dim3(ceil_div(n_points_max, kBlock), n_theta_max, nq),
+                           dim3(kBlock), 0, ctx->stream, reinterpret_cast<const IndexJob*>(d_ij));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+        if ((rc = set_lds(ctx, k_bin_batch, bin_lds))) return rc;
+        ScopedTimer tm(ctx, "bin");
+        hipLaunchKernelGGL(k_bin_batch, dim3(n_theta_max, nq), dim3(kBlock), bin_lds, ctx->stream,
+                           reinterpret_cast<const BinJob*>(d_bj));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    for (int h = H; h >= 1; --h) {
+        const int st = 1 << h;
+        const int nxh = nx >> h, nyh = ny >> h;
+        int c_cbx = std::min(nxh, (lstride - kTile - 8) / st + 1);
+        const int c_ncbx = ceil_div(nxh, c_cbx);
+        c_cbx = ceil_div(nxh, c_ncbx);
+        int cg = std::max(1, kBlock / c_cbx);
+        cg = std::min(cg, 64 / st + 1);
+        cg = std::min(cg, nyh);
+        const int c_ncby = ceil_div(nyh, cg);
+        /* keep >= ~2k workgroups in flight: split the tile list when the
+         * level has few candidate blocks */
+        const long blocks = (long)c_ncbx * c_ncby * n_theta_max * nq;
+        const int n_slices = blocks >= 4096 ? 1 : (int)std::min<long>(8, ceil_div(4096, (int)std::max<long>(1, blocks)));
+        ScopedTimer tm(ctx, "score_coarse");
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[h]), nq, lstride, 1,
+                                     true, st, c_cbx, cg, c_ncbx * c_ncby, n_theta_max, n_slices)))
+            return rc;
+    }
+    {
+        ScopedTimer tm(ctx, "score_fine");
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lstride, R,
+                                     false, 1, cbx, groups, ncb, n_theta_max, 1)))
+            return rc;
+    }
+    {
+        const size_t lds = (size_t)n_points_max * 8;
+        if ((rc = set_lds(ctx, k_finalize_batch, lds))) return rc;
+        ScopedTimer tm(ctx, "finalize");
+        hipLaunchKernelGGL(k_finalize_batch, dim3(nq), dim3(kBlock), lds, ctx->stream,
+                           reinterpret_cast<const FinalJob*>(d_fj));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    std::vector<csm_result> res(nq);
+    HIP_TRY(ctx, hipMemcpyAsync(res.data(), d_out, (size_t)nq * sizeof(csm_result),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    for (int k = 0; k < nq; ++k) {
+        const csm_loop_query& q = queries[idx[k]];
+        csm_summary& o = out[idx[k]];
+        o.raw = res[k];
+        o.pose_found = o.raw.found;
+        /* scan_matcher_branch_bound.cpp:238-247 */
+        o.best_sensor_pose[0] = o.sensor_pose[0] + o.step_x * o.raw.best_x;
+        o.best_sensor_pose[1] = o.sensor_pose[1] + o.step_y * o.raw.best_y;
+        o.best_sensor_pose[2] = o.sensor_pose[2] + o.step_theta * o.raw.best_theta;
+        csm_host_move_backward(o.best_sensor_pose, q.scan.relative_sensor_pose, o.estimated_pose);
+        o.candidates = (int64_t)pp[k].n_theta * nx * ny;
+    }
+    return CSM_OK;
+}
+
+} /* namespace */
+
+extern "C" {
+
+int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_queries,
+                        const csm_bnb_params* prm, csm_summary* out)
+{
+    if (!ctx || !queries || n_queries < 1 || !prm || !out || prm->node_height_max < 0 ||
+        prm->node_height_max >= kMaxElig)
+        return fail(ctx, CSM_EINVAL, "csm_bnb_match_batch: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int H = prm->node_height_max;
+    const auto t0 = std::chrono::steady_clock::now();
+    /* pyramids: build and cache per map id, as mPrecompMaps does
+     * (loop_detector_branch_bound.cpp:83-89) */
+    std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
+    for (int i = 0; i < n_queries; ++i) {
+        if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
+            return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
+        DeviceGrid* g = find_grid(ctx, queries[i].map_id);
+        if (!g)
+            return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
+                        (unsigned long long)queries[i].map_id);
+        for (int h = 0; h <= H; ++h) {
+            int rc = level_for_window(ctx, *g, 1 << h, &levels[i][h]);
+            if (rc)
+                return rc;
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+
+    /* group queries by leaf-window shape */
+    std::memset(out, 0, sizeof(csm_summary) * (size_t)n_queries);
+    std::map<std::pair<int, int>, std::vector<int>> groups;
+    for (int i = 0; i < n_queries; ++i) {
+        double sx, sy, st;
+        csm_host_search_step(queries[i].geometry.resolution, queries[i].scan.ranges,
+                             queries[i].scan.n_points, &sx, &sy, &st);
+        const int big = 1 << H;
+        const int nx = ceil_div(2 * csm_host_window(prm->range_x, sx) + 1, big) * big;
+        const int ny = ceil_div(2 * csm_host_window(prm->range_y, sy) + 1, big) * big;
+        groups[{ nx, ny }].push_back(i);
+    }
+    for (auto& kv : groups) {
+        int rc = run_bnb_group(ctx, queries, kv.second, levels, prm, out);
+        if (rc)
+            return rc;
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    const double setup = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    const double opt = std::chrono::duration<double, std::micro>(t2 - t1).count();
+    for (int i = 0; i < n_queries; ++i) {
+        out[i].input_setup_us = setup / n_queries;
+        out[i].optimization_us = opt / n_queries;
+    }
+    return CSM_OK;
 }
 
 /* ---- measurement hooks ---- */

@@ -31,7 +31,7 @@ struct BlockBest {
 
 /* Known-count array of a coarser level: K[t][xi / div][yi / div]. */
 struct EligLevel {
-    const uint16_t* k;
+    const uint32_t* k;
     const uint32_t* s;         /* raw-value sums of the same nodes (bound check) */
     int32_t div;
     int32_t nxc, nyc;
@@ -71,6 +71,8 @@ struct ScoreJob {
     /* outputs (any may be null) */
     uint32_t*  dump_s;         /* [n_theta][nx][ny] */
     uint16_t*  dump_k;         /* [n_theta][nx][ny] */
+    uint32_t*  acc_s;          /* [n_theta][nx][ny] atomic accumulate (tile-split launches) */
+    uint32_t*  acc_k;
     BlockBest* block_best;     /* [n_theta][n_cand_blocks] */
     uint32_t*  flags;          /* [1] query flags (band touch in, edge band out) */
     /* eligibility for the argmax */
@@ -97,6 +99,22 @@ struct FinalJob {
     const double* lut;
     const uint32_t* flags_in;
     void* out;                 /* csm_result* (device) */
+};
+
+/* Branch-and-bound projection: per (theta, beam) products r*cos / r*sin come
+ * from the host (glibc), the device derives the base cell indices and checks
+ * that every per-node projection equals base + offset. */
+struct IndexJob {
+    const double* r_cos;       /* [n_theta][n_points] */
+    const double* r_sin;
+    int32_t* hit_col;          /* [n_theta][n_points] out */
+    int32_t* hit_row;
+    uint32_t* flags;           /* [1] CSM_FLAG_PROJ_DELTA */
+    int32_t n_theta, n_points;
+    int32_t x_lo, y_lo, nx, ny;
+    double sensor_x, sensor_y;
+    double step_x, step_y;
+    double off_x, off_y, res;
 };
 
 } /* namespace csm */

@@ -51,7 +51,7 @@ __device__ __forceinline__ int band_index(int u, int w, int nk)
 }
 
 /* ------------------------------------------------------------------ K0 */
-__global__ __launch_bounds__(kBlock) void k_bin(BinJob job)
+__device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
     extern __shared__ uint32_t sm_bin[];
     const int ntile = job.tiles_x * job.tiles_y;
@@ -144,6 +144,11 @@ __global__ __launch_bounds__(kBlock) void k_bin(BinJob job)
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_bin(BinJob job)
+{
+    k_bin_body(job);
+}
+
 /* ------------------------------------------------------------------ K1 */
 
 __device__ __forceinline__ void best_combine(unsigned long long& key,
@@ -173,7 +178,8 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 /* LSTRIDE: LDS row pitch in cells. R: candidate rows per lane.
  * STRIDED: candidates are `stride` cells apart (coarser levels). */
 template <int LSTRIDE, int R, bool STRIDED>
-__device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups)
+__device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups,
+                                           int slice, int n_slices)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
     __shared__ unsigned long long red_key[kBlock / 64];
@@ -213,7 +219,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     const uint32_t* pbs = job.sorted_pb + (size_t)t * job.n_points;
     constexpr int kChunks = LSTRIDE / 8;
 
-    for (int ti = 0; ti < ntiles; ++ti) {
+    for (int ti = slice; ti < ntiles; ti += n_slices) {
         const TileRec rec = recs[ti];
         const int cs = (rec.c0 + x0) & ~7;          /* 16-byte aligned first col */
         const int a = (rec.c0 + x0) - cs;           /* 0..7 */
@@ -263,6 +269,13 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                 job.dump_s[ci] = S[r];
             if (job.dump_k)
                 job.dump_k[ci] = (uint16_t)K[r];
+            if (job.acc_s) {
+                /* tile-split launch: slices add their partial integer sums */
+                if (S[r])
+                    atomicAdd(&job.acc_s[ci], S[r]);
+                if (K[r])
+                    atomicAdd(&job.acc_k[ci], K[r]);
+            }
             if (!job.block_best)
                 continue;
             bool ok = !job.check_own_known || (int)K[r] >= job.min_known;
@@ -323,16 +336,20 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     }
 }
 
+/* grid = (candidate blocks, theta slices, tile slices) */
 template <int LSTRIDE, int R, bool STRIDED>
 __global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups)
 {
-    score_body<LSTRIDE, R, STRIDED>(job, cbx, groups);
+    score_body<LSTRIDE, R, STRIDED>(job, cbx, groups, blockIdx.z, gridDim.z);
 }
 
+/* grid = (candidate blocks, theta slices, jobs * n_slices) */
 template <int LSTRIDE, int R, bool STRIDED>
-__global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups)
+__global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups,
+                                                       int n_slices)
 {
-    score_body<LSTRIDE, R, STRIDED>(jobs[blockIdx.z], cbx, groups);
+    score_body<LSTRIDE, R, STRIDED>(jobs[blockIdx.z / n_slices], cbx, groups,
+                                    blockIdx.z % n_slices, n_slices);
 }
 
 /* ------------------------------------------------------------------ K2 */
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_boxmax_h(const uint16_t* in, uint16_
 }
 
 /* ------------------------------------------------------------------ K4 */
-__global__ __launch_bounds__(kBlock) void k_finalize(FinalJob job)
+__device__ __forceinline__ void k_finalize_body(const FinalJob& job)
 {
     extern __shared__ double sm_p[];            /* [n_points] probabilities */
     __shared__ unsigned long long red_key[kBlock];
@@ -451,12 +468,21 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinalJob job)
     red_k[tid] = k;
     __syncthreads();
     if (tid == 0) {
+        /* beam order, one rounding per add; adding the 0.0 of an unknown
+         * cell is exact, so no skip is needed */
         double sum = 0.0;
-        for (int i = 0; i < job.n_points; ++i) {
-            const double p = sm_p[i];
-            if (p != 0.0)
-                sum += p;
+        int i = 0;
+        for (; i + 8 <= job.n_points; i += 8) {
+            double p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                p[j] = sm_p[i + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                sum += p[j];
         }
+        for (; i < job.n_points; ++i)
+            sum += sm_p[i];
         uint32_t st = 0, kt = 0;
         for (int i = 0; i < kBlock; ++i) {
             st += red_s[i];
@@ -481,6 +507,79 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinalJob job)
         }
         *out = r;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalize(FinalJob job)
+{
+    k_finalize_body(job);
+}
+
+/* ------------------------------------------------------------------ batch */
+__global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
+{
+    /* k_bin reads blockIdx.x as the theta slice */
+    k_bin_body(jobs[blockIdx.y]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalize_batch(const FinalJob* jobs)
+{
+    k_finalize_body(jobs[blockIdx.x]);
+}
+
+/* PositionToIndex on device, IEEE double, no contraction: bit-identical to
+ * src/grid_map_new/grid_map_geometry.cpp:113-122 */
+__device__ __forceinline__ int cell_index(double pos, double off, double res)
+{
+    return (int)floor((pos - off) / res);
+}
+
+/* Does floor((hit - off) / res) equal `expect`? Cheap certified test first
+ * (multiply by the reciprocal, margin far above its rounding error), exact
+ * division only next to a cell edge. */
+__device__ __forceinline__ bool index_is(double hit, double off, double res, double inv_res,
+                                         int expect)
+{
+    const double t = hit - off;
+    const double q = t * inv_res;
+    const double e = (double)expect;
+    const double margin = 1e-9 * (fabs(e) + 1.0);
+    if (q > e + margin && q < e + 1.0 - margin)
+        return true;
+    return (int)floor(t / res) == expect;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bnb_index(const IndexJob* jobs)
+{
+    const IndexJob& job = jobs[blockIdx.z];
+    const int t = blockIdx.y;
+    if (t >= job.n_theta)
+        return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= job.n_points)
+        return;
+    const size_t idx = (size_t)t * job.n_points + i;
+    const double rc = job.r_cos[idx], rs = job.r_sin[idx];
+    /* ScanData::HitPoint at the un-shifted sensor pose */
+    const int col = cell_index(job.sensor_x + rc, job.off_x, job.res);
+    const int row = cell_index(job.sensor_y + rs, job.off_y, job.res);
+    job.hit_col[idx] = col;
+    job.hit_row[idx] = row;
+    /* appendNode's pose: sensor + x * step, then HitPoint, then PositionToIndex
+     * (src/mapping/scan_matcher_branch_bound.cpp:156-176) */
+    const double inv_res = 1.0 / job.res;
+    bool delta = false;
+    for (int xi = 0; xi < job.nx; ++xi) {
+        const int x = job.x_lo + xi;
+        const double px = job.sensor_x + x * job.step_x;
+        delta |= !index_is(px + rc, job.off_x, job.res, inv_res, col + x);
+    }
+    for (int yi = 0; yi < job.ny; ++yi) {
+        const int y = job.y_lo + yi;
+        const double py = job.sensor_y + y * job.step_y;
+        delta |= !index_is(py + rs, job.off_y, job.res, inv_res, row + y);
+    }
+    if (delta)
+        atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
 }
 
 } /* namespace csm */
