@@ -218,6 +218,13 @@ int  csm_score_window(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
 int  csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
                           const int32_t* hit_col_dev, const int32_t* hit_row_dev,
                           csm_result* out_dev);
+/* Synchronises, reads *out_dev and, when it carries a key tie or an edge-band
+ * flag, runs the exact device paths (f64 tie replay / literal sequential
+ * sweep) for the window just scored with csm_score_window_dev(); no-op
+ * otherwise. csm_score_window() does this itself. */
+int  csm_resolve_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
+                            const int32_t* hit_col_dev, const int32_t* hit_row_dev,
+                            csm_result* out_dev);
 /* Optional dump of every candidate's integer sums for parity tests:
  * S [n_theta][nx][ny] uint32 and K [..] uint16 (nx = ceil((2*win_x+1)/L)*L),
  * coarse K [n_theta][nx/L][ny/L]. Host pointers, any may be NULL. */

@@ -13,7 +13,7 @@ def _segments_of_box(x0, y0, x1, y1):
 
 
 def make_room(seed, rows=400, cols=400, res=0.05, half_x=None, half_y=None,
-              n_boxes=6, levels=None, interior_unknown=0.03):
+              n_boxes=6, levels=None, interior_unknown=0.03, origin="center"):
     """Returns (grid uint16 [rows, cols], geom (res, offX, offY), segments).
 
     levels: None -> walls in [50000, 52000], free in [3000, 5000] (many distinct
@@ -26,6 +26,17 @@ def make_room(seed, rows=400, cols=400, res=0.05, half_x=None, half_y=None,
     off_y = -0.5 * ext_y - 0.0219 + 0.01 * rng.rand()
     hx = half_x if half_x is not None else ext_x * (0.26 + 0.08 * rng.rand())
     hy = half_y if half_y is not None else ext_y * (0.20 + 0.08 * rng.rand())
+    if origin == "low_edge":
+        # the room's low walls sit 1-2 cells inside the map's low edges, so
+        # scan points project into / next to the negative edge band
+        off_x = -hx - 1.6 * res
+        off_y = -hy - 1.4 * res
+    elif origin == "aligned":
+        # everything on exact multiples of the resolution: points on cell edges
+        off_x = -0.5 * ext_x
+        off_y = -0.5 * ext_y
+        hx = round(hx / res) * res
+        hy = round(hy / res) * res
     segs = _segments_of_box(-hx, -hy, hx, hy)
     boxes = []
     for _ in range(n_boxes):
@@ -97,9 +108,9 @@ def cast_scan(segs, pose, n_beams=360, fov=2 * math.pi, max_range=5.7296, noise=
 
 def csm_case(seed, rows=400, cols=400, res=0.05, n_beams=360, fov=2 * math.pi,
              max_range=5.7296, levels=None, init_error=(0.17, -0.12, 0.02),
-             rel_pose=(0.0, 0.0, 0.0), truth=None):
+             rel_pose=(0.0, 0.0, 0.0), truth=None, origin="center", **room_kw):
     """One scan-vs-map case: grid + geometry + scan + initial pose."""
-    grid, geom, segs = make_room(seed, rows, cols, res, levels=levels)
+    grid, geom, segs = make_room(seed, rows, cols, res, levels=levels, origin=origin, **room_kw)
     rng = np.random.RandomState(seed + 7919)
     if truth is None:
         truth = (0.013 + 0.4 * (rng.rand() - 0.5), -0.021 + 0.4 * (rng.rand() - 0.5),

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -64,6 +65,10 @@ struct csm_ctx {
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
+    DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k;
+    /* the fine-level job of the last csm window, for the tie collection pass */
+    csm::ScoreJob last_fine;
+    int last_lstride = 0, last_R = 0, last_cbx = 0, last_groups = 0, last_ncb = 0;
     bool timing = false;
     std::map<std::string, KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -492,6 +497,12 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         if ((rc = launch_score(ctx, fj, p.lstride, p.R, false, p.cbx, p.groups, ncb, p.n_theta, 1)))
             return rc;
     }
+    ctx->last_fine = fj;
+    ctx->last_lstride = p.lstride;
+    ctx->last_R = p.R;
+    ctx->last_cbx = p.cbx;
+    ctx->last_groups = p.groups;
+    ctx->last_ncb = ncb;
 
     FinalJob fin;
     std::memset(&fin, 0, sizeof(fin));
@@ -524,6 +535,149 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), lds, ctx->stream, fin);
         HIP_TRY(ctx, hipGetLastError());
     }
+    return CSM_OK;
+}
+
+
+const uint32_t kTieCap = 1u << 16;
+
+/* Several candidates share the best integer key: collect them with a second
+ * fine pass, replay each in f64, pick like the reference's strict `<`. */
+int resolve_ties(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
+                 const int32_t* col_dev, const int32_t* row_dev, csm_result* out_dev)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->tie, (size_t)kTieCap * 16 + 64))) return rc;
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(ctx->tie.p);
+    double* score = reinterpret_cast<double*>(list + kTieCap);
+    uint32_t* count = reinterpret_cast<uint32_t*>(score + kTieCap);
+    HIP_TRY(ctx, hipMemsetAsync(count, 0, 4, ctx->stream));
+    ScoreJob cj = ctx->last_fine;
+    cj.block_best = nullptr;
+    cj.dump_s = nullptr;
+    cj.dump_k = nullptr;
+    cj.collect_key = reinterpret_cast<const unsigned long long*>(
+        reinterpret_cast<const char*>(out_dev) + offsetof(csm_result, key));
+    cj.tie_list = list;
+    cj.tie_count = count;
+    cj.tie_cap = kTieCap;
+    if ((rc = launch_score(ctx, cj, ctx->last_lstride, ctx->last_R, false, ctx->last_cbx,
+                           ctx->last_groups, ctx->last_ncb, p.n_theta, 1)))
+        return rc;
+    TieJob tj;
+    std::memset(&tj, 0, sizeof(tj));
+    tj.tie_list = list;
+    tj.tie_count = count;
+    tj.tie_cap = kTieCap;
+    tj.tie_score = score;
+    tj.nx = p.nx;
+    tj.ny = p.ny;
+    tj.rank_l = p.L;
+    tj.x_lo = p.x_lo;
+    tj.y_lo = p.y_lo;
+    tj.win_theta = (p.n_theta - 1) / 2;
+    tj.cells = g.levels[0].cells;
+    tj.rows = g.rows;
+    tj.cols = g.cols;
+    tj.pitch = g.pitch;
+    tj.hit_col = col_dev;
+    tj.hit_row = row_dev;
+    tj.n_points = p.n;
+    tj.score_thr = w->score_threshold;
+    tj.lut = ctx->lut_dev;
+    tj.out = out_dev;
+    uint32_t n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    n = std::min(n, kTieCap);
+    if (n == 0)
+        return CSM_OK;
+    const size_t lds = (size_t)p.n * 8;
+    if ((rc = set_lds(ctx, k_tie_replay, lds))) return rc;
+    hipLaunchKernelGGL(k_tie_replay, dim3(n), dim3(kBlock), lds, ctx->stream, tj);
+    hipLaunchKernelGGL(k_tie_pick, dim3(1), dim3(64), 0, ctx->stream, tj);
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
+/* The reference's sequential sweep over device-computed exact scores: used
+ * when some coarse node fails to bound its fine candidates (negative edge
+ * band) or the tie list overflows. */
+int resolve_literal(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
+                    const int32_t* col_dev, const int32_t* row_dev, csm_result* out_dev)
+{
+    int rc;
+    const size_t nf = (size_t)p.n_theta * p.nx * p.ny;
+    const size_t nc = (size_t)p.n_theta * p.nxc * p.nyc;
+    if ((rc = ensure(ctx, ctx->ex_fine, nf * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->ex_fine_k, nf * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ex_coarse, nc * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->ex_coarse_k, nc * 4))) return rc;
+    ExactJob ej;
+    std::memset(&ej, 0, sizeof(ej));
+    ej.rows = g.rows;
+    ej.cols = g.cols;
+    ej.pitch = g.pitch;
+    ej.hit_col = col_dev;
+    ej.hit_row = row_dev;
+    ej.n_theta = p.n_theta;
+    ej.n_points = p.n;
+    ej.x_lo = p.x_lo;
+    ej.y_lo = p.y_lo;
+    ej.lut = ctx->lut_dev;
+    ExactJob cj = ej;
+    cj.cells = g.levels[w->coarse_level].cells;
+    cj.nx = p.nxc;
+    cj.ny = p.nyc;
+    cj.stride = p.L;
+    cj.out_score = reinterpret_cast<double*>(ctx->ex_coarse.p);
+    cj.out_k = reinterpret_cast<uint32_t*>(ctx->ex_coarse_k.p);
+    hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((nc + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, cj);
+    ExactJob fj = ej;
+    fj.cells = g.levels[0].cells;
+    fj.nx = p.nx;
+    fj.ny = p.ny;
+    fj.stride = 1;
+    fj.out_score = reinterpret_cast<double*>(ctx->ex_fine.p);
+    fj.out_k = reinterpret_cast<uint32_t*>(ctx->ex_fine_k.p);
+    hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, fj);
+    LiteralJob lj;
+    std::memset(&lj, 0, sizeof(lj));
+    lj.coarse_score = cj.out_score;
+    lj.coarse_k = cj.out_k;
+    lj.fine_score = fj.out_score;
+    lj.n_theta = p.n_theta;
+    lj.nxc = p.nxc;
+    lj.nyc = p.nyc;
+    lj.L = p.L;
+    lj.x_lo = p.x_lo;
+    lj.y_lo = p.y_lo;
+    lj.win_theta = (p.n_theta - 1) / 2;
+    lj.min_known = w->min_known;
+    lj.score_thr = w->score_threshold;
+    lj.out = out_dev;
+    hipLaunchKernelGGL(k_csm_literal_scan, dim3(1), dim3(64), 0, ctx->stream, lj);
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
+/* Finish a window whose fast-path record carries a tie or an edge-band flag. */
+int resolve_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
+                   const int32_t* col_dev, const int32_t* row_dev, csm_result* out_dev)
+{
+    csm_result r;
+    HIP_TRY(ctx, hipMemcpyAsync(&r, out_dev, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if (!(r.flags & CSM_FLAG_EDGE_BAND) && r.tie_count > 1) {
+        if ((rc = resolve_ties(ctx, g, w, p, col_dev, row_dev, out_dev))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(&r, out_dev, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (r.flags & CSM_FLAG_EDGE_BAND)
+        if ((rc = resolve_literal(ctx, g, w, p, col_dev, row_dev, out_dev))) return rc;
     return CSM_OK;
 }
 
@@ -576,7 +730,8 @@ int csm_destroy(csm_ctx* ctx)
     DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
-                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out };
+                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
+                       &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k };
     for (DevBuf* b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -832,6 +987,22 @@ int csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
     return run_window(ctx, *g, w, p, hit_col_dev, hit_row_dev, out_dev, nullptr);
 }
 
+int csm_resolve_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
+                           const int32_t* hit_col_dev, const int32_t* hit_row_dev,
+                           csm_result* out_dev)
+{
+    if (!ctx || !w || !hit_col_dev || !hit_row_dev || !out_dev)
+        return fail(ctx, CSM_EINVAL, "csm_resolve_window_dev: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    Plan p;
+    int rc = make_plan(ctx, *g, w, &p);
+    if (rc)
+        return rc;
+    return resolve_window(ctx, *g, w, p, hit_col_dev, hit_row_dev, out_dev);
+}
+
 int csm_score_window_dump(csm_ctx* ctx, uint64_t map_id, const csm_window* w, const int32_t* hit_col,
                           const int32_t* hit_row, csm_result* out, uint32_t* dump_s,
                           uint16_t* dump_k, uint16_t* dump_coarse_k)
@@ -865,6 +1036,8 @@ int csm_score_window_dump(csm_ctx* ctx, uint64_t map_id, const csm_window* w, co
     }
     rc = run_window(ctx, *g, w, p, col_dev, row_dev, res_dev, (dump_s || dump_k) ? &dumps : nullptr);
     if (rc)
+        return rc;
+    if ((rc = resolve_window(ctx, *g, w, p, col_dev, row_dev, res_dev)))
         return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost, ctx->stream));
     if (dump_s)
@@ -1017,6 +1190,118 @@ struct BnbPrep {
     size_t hit_off = 0, tile_off = 0, theta_off = 0, best_off = 0;
     size_t lvl_off[kMaxElig] = { 0 };
 };
+
+
+/* Node of the reference's best-first search
+ * (inc/mapping/scan_matcher_branch_bound.hpp:67-106): ordered by score only. */
+struct HeapNode {
+    int x, y, t, h;
+    double score, known_rate;
+    bool operator<(const HeapNode& o) const { return score < o.score; }
+};
+
+/* Exact resolution of one flagged branch-and-bound query. The device computes
+ * the f64 score (beam order, per-node projection in double) and known count of
+ * EVERY node of every level; the host then runs the reference's queue
+ * discipline (std::priority_queue, same push / pop order as
+ * src/mapping/scan_matcher_branch_bound.cpp:156-231) reading those scores
+ * instead of calling Score(). No score is computed on the CPU. */
+int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BnbPrep& p, const csm_summary& o,
+                const csm_bnb_params* prm, const double* d_rc, const double* d_rs,
+                csm_result* res)
+{
+    const int H = prm->node_height_max;
+    const int nx = p.nx, ny = p.ny;
+    std::vector<std::vector<double>> sc(H + 1);
+    std::vector<std::vector<uint32_t>> kn(H + 1);
+    int rc;
+    for (int h = 0; h <= H; ++h) {
+        const int nxh = nx >> h, nyh = ny >> h;
+        const size_t n = (size_t)p.n_theta * nxh * nyh;
+        if ((rc = ensure(ctx, ctx->ex_fine, n * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->ex_fine_k, n * 4))) return rc;
+        ExactJob ej;
+        std::memset(&ej, 0, sizeof(ej));
+        ej.cells = p.grid->levels[p.level[h]].cells;
+        ej.rows = p.grid->rows;
+        ej.cols = p.grid->cols;
+        ej.pitch = p.grid->pitch;
+        ej.r_cos = d_rc;
+        ej.r_sin = d_rs;
+        ej.sensor_x = o.sensor_pose[0];
+        ej.sensor_y = o.sensor_pose[1];
+        ej.step_x = o.step_x;
+        ej.step_y = o.step_y;
+        ej.off_x = q.geometry.offset_x;
+        ej.off_y = q.geometry.offset_y;
+        ej.res = q.geometry.resolution;
+        ej.n_theta = p.n_theta;
+        ej.n_points = p.n;
+        ej.x_lo = -p.win_x;
+        ej.y_lo = -p.win_y;
+        ej.nx = nxh;
+        ej.ny = nyh;
+        ej.stride = 1 << h;
+        ej.lut = ctx->lut_dev;
+        ej.out_score = reinterpret_cast<double*>(ctx->ex_fine.p);
+        ej.out_k = reinterpret_cast<uint32_t*>(ctx->ex_fine_k.p);
+        hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
+                           0, ctx->stream, ej);
+        HIP_TRY(ctx, hipGetLastError());
+        sc[h].resize(n);
+        kn[h].resize(n);
+        HIP_TRY(ctx, hipMemcpyAsync(sc[h].data(), ej.out_score, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(kn[h].data(), ej.out_k, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+
+    const int win_x = p.win_x, win_y = p.win_y, win_t = p.win_t;
+    double score_max = prm->score_threshold;
+    int best_x = 0, best_y = 0, best_t = 0;
+    std::priority_queue<HeapNode> queue;
+    const double n_points = static_cast<double>(p.n);
+    auto append_node = [&](int x, int y, int t, int h) {
+        const int xi = (x + win_x) >> h, yi = (y + win_y) >> h;
+        const size_t i = ((size_t)(t + win_t) * (nx >> h) + xi) * (ny >> h) + yi;
+        const double score = sc[h][i];
+        if (score > score_max)
+            queue.push(HeapNode { x, y, t, h, score, static_cast<double>(kn[h][i]) / n_points });
+    };
+    const int win_size_max = 1 << H;
+    for (int x = -win_x; x <= win_x; x += win_size_max)
+        for (int y = -win_y; y <= win_y; y += win_size_max)
+            for (int t = -win_t; t <= win_t; ++t)
+                append_node(x, y, t, H);
+    while (!queue.empty()) {
+        const HeapNode cur = queue.top();
+        if (cur.score <= score_max || cur.known_rate <= prm->known_rate_threshold) {
+            queue.pop();
+            continue;
+        }
+        if (cur.h == 0) {
+            best_x = cur.x;
+            best_y = cur.y;
+            best_t = cur.t;
+            score_max = cur.score;
+            queue.pop();
+        } else {
+            const int h = cur.h - 1;
+            const int wsz = 1 << h;
+            queue.pop();
+            append_node(cur.x, cur.y, cur.t, h);
+            append_node(cur.x + wsz, cur.y, cur.t, h);
+            append_node(cur.x, cur.y + wsz, cur.t, h);
+            append_node(cur.x + wsz, cur.y + wsz, cur.t, h);
+        }
+    }
+    res->found = score_max > prm->score_threshold ? 1 : 0;
+    res->best_x = best_x;
+    res->best_y = best_y;
+    res->best_theta = best_t;
+    res->score = score_max;
+    res->flags |= CSM_FLAG_LITERAL;
+    return CSM_OK;
+}
 
 /* One group of queries that share (nx, ny): the whole device pipeline. */
 int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector<int>& idx,
@@ -1348,6 +1633,10 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     for (int k = 0; k < nq; ++k) {
         const csm_loop_query& q = queries[idx[k]];
         csm_summary& o = out[idx[k]];
+        if (res[k].flags & (CSM_FLAG_EDGE_BAND | CSM_FLAG_KEY_TIE | CSM_FLAG_PROJ_DELTA))
+            if ((rc = bnb_literal(ctx, q, pp[k], o, prm, d_rc + pp[k].hit_off, d_rs + pp[k].hit_off,
+                                  &res[k])))
+                return rc;
         o.raw = res[k];
         o.pose_found = o.raw.found;
         /* scan_matcher_branch_bound.cpp:238-247 */

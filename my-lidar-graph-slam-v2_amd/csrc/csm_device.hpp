@@ -74,6 +74,12 @@ struct ScoreJob {
     uint32_t*  acc_s;          /* [n_theta][nx][ny] atomic accumulate (tile-split launches) */
     uint32_t*  acc_k;
     BlockBest* block_best;     /* [n_theta][n_cand_blocks] */
+    /* tie collection pass: append the rank of every eligible candidate whose
+     * key equals *collect_key */
+    const unsigned long long* collect_key;
+    unsigned long long* tie_list;
+    uint32_t*  tie_count;
+    uint32_t   tie_cap;
     uint32_t*  flags;          /* [1] query flags (band touch in, edge band out) */
     /* eligibility for the argmax */
     int32_t n_elig;
@@ -115,6 +121,52 @@ struct IndexJob {
     double sensor_x, sensor_y;
     double step_x, step_y;
     double off_x, off_y, res;
+};
+
+/* Exhaustive f64 scores (beam order) of one level; literal / tie paths. */
+struct ExactJob {
+    const uint16_t* cells;
+    int32_t rows, cols, pitch;
+    const int32_t* hit_col;    /* integer-offset projection (CSM) */
+    const int32_t* hit_row;
+    const double* r_cos;       /* per-node projection (branch and bound) when non-null */
+    const double* r_sin;
+    double sensor_x, sensor_y, step_x, step_y, off_x, off_y, res;
+    int32_t n_theta, n_points;
+    int32_t x_lo, y_lo, nx, ny, stride;
+    const double* lut;
+    double*   out_score;       /* [n_theta][nx][ny] normalized score */
+    uint32_t* out_k;           /* [n_theta][nx][ny] known count */
+};
+
+/* f64 replay of a list of tied candidates + pick (CSM order). */
+struct TieJob {
+    const unsigned long long* tie_list;
+    const uint32_t* tie_count;
+    uint32_t tie_cap;
+    double* tie_score;         /* [tie_cap] */
+    int32_t nx, ny, rank_l, x_lo, y_lo, win_theta;
+    const uint16_t* cells;
+    int32_t rows, cols, pitch;
+    const int32_t* hit_col;
+    const int32_t* hit_row;
+    int32_t n_points;
+    double score_thr;
+    const double* lut;
+    void* out;                 /* csm_result*, updated in place */
+};
+
+/* Literal sequential sweep of ScanMatcherCorrelative over precomputed exact
+ * scores (src/mapping/scan_matcher_correlative.cpp:161-197, 339-368). */
+struct LiteralJob {
+    const double*   coarse_score;  /* [n_theta][nxc][nyc] */
+    const uint32_t* coarse_k;
+    const double*   fine_score;    /* [n_theta][nx][ny] */
+    int32_t n_theta, nxc, nyc, L;
+    int32_t x_lo, y_lo, win_theta;
+    int32_t min_known;
+    double score_thr;
+    void* out;                     /* csm_result* */
 };
 
 } /* namespace csm */

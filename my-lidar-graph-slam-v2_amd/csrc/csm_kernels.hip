@@ -50,6 +50,13 @@ __device__ __forceinline__ int band_index(int u, int w, int nk)
     return (v <= -1 && v >= -(w - 1)) ? k0 : -1;
 }
 
+/* PositionToIndex on device, IEEE double, no contraction: bit-identical to
+ * src/grid_map_new/grid_map_geometry.cpp:113-122 */
+__device__ __forceinline__ int cell_index(double pos, double off, double res)
+{
+    return (int)floor((pos - off) / res);
+}
+
 /* ------------------------------------------------------------------ K0 */
 __device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
@@ -257,7 +264,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     uint32_t bcnt = 0;
     bool bound_broken = false;
     const bool band_touch =
-        job.block_best && job.n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
+        (job.block_best || job.tie_list) && job.n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
     if (lane_on && xi < job.nx) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -276,7 +283,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                 if (K[r])
                     atomicAdd(&job.acc_k[ci], K[r]);
             }
-            if (!job.block_best)
+            if (!job.block_best && !job.tie_list)
                 continue;
             bool ok = !job.check_own_known || (int)K[r] >= job.min_known;
             const unsigned long long key =
@@ -299,10 +306,18 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
             bound_broken |= broken;
             if (key == 0)
                 continue;
+            if (job.tie_list && key != *job.collect_key)
+                continue;
             const int L = job.rank_l;
             const int nxc = job.nx / L, nyc = job.ny / L;
             const unsigned long long rank =
                 ((((unsigned long long)t * nxc + xi / L) * nyc + yi / L) * L + xi % L) * L + yi % L;
+            if (job.tie_list) {
+                const uint32_t pos = atomicAdd(job.tie_count, 1u);
+                if (pos < job.tie_cap)
+                    job.tie_list[pos] = rank;
+                continue;
+            }
             best_combine(bkey, brank, bcnt, key, rank, 1u);
         }
     }
@@ -514,6 +529,219 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinalJob job)
     k_finalize_body(job);
 }
 
+/* ------------------------------------------------------------------ exact paths */
+
+/* Every candidate of one level, f64 in beam order: what the reference's
+ * ComputeScore / ScorePixelAccurate::Score returns. One lane per candidate. */
+__global__ __launch_bounds__(kBlock) void k_exact_scores(ExactJob job)
+{
+    const long total = (long)job.n_theta * job.nx * job.ny;
+    const long gid = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= total)
+        return;
+    const int yi = (int)(gid % job.ny);
+    const int xi = (int)((gid / job.ny) % job.nx);
+    const int t = (int)(gid / ((long)job.ny * job.nx));
+    const int x = job.x_lo + xi * job.stride, y = job.y_lo + yi * job.stride;
+    const size_t base = (size_t)t * job.n_points;
+    double sum = 0.0;
+    uint32_t known = 0;
+    const bool per_node = job.r_cos != nullptr;
+    const double px = job.sensor_x + x * job.step_x;
+    const double py = job.sensor_y + y * job.step_y;
+    for (int i = 0; i < job.n_points; ++i) {
+        int r, c;
+        if (per_node) {
+            c = cell_index(px + job.r_cos[base + i], job.off_x, job.res);
+            r = cell_index(py + job.r_sin[base + i], job.off_y, job.res);
+        } else {
+            c = job.hit_col[base + i] + x;
+            r = job.hit_row[base + i] + y;
+        }
+        uint32_t v = 0;
+        if (r >= 0 && r < job.rows && c >= 0 && c < job.cols)
+            v = job.cells[(size_t)r * job.pitch + c];
+        sum += job.lut[v];
+        known += v != 0;
+    }
+    job.out_score[gid] = sum / (double)job.n_points;
+    job.out_k[gid] = known;
+}
+
+/* One workgroup per tied candidate: exact score, as k_finalize does. */
+__global__ __launch_bounds__(kBlock) void k_tie_replay(TieJob job)
+{
+    extern __shared__ double sm_tp[];
+    const uint32_t n = min(*job.tie_count, job.tie_cap);
+    if (blockIdx.x >= n)
+        return;
+    const int L = job.rank_l;
+    const int nxc = job.nx / L, nyc = job.ny / L;
+    unsigned long long q = job.tie_list[blockIdx.x];
+    const int fy = (int)(q % L); q /= L;
+    const int fx = (int)(q % L); q /= L;
+    const int yc = (int)(q % nyc); q /= nyc;
+    const int xc = (int)(q % nxc); q /= nxc;
+    const int t = (int)q;
+    const int x = job.x_lo + xc * L + fx, y = job.y_lo + yc * L + fy;
+    const int32_t* col = job.hit_col + (size_t)t * job.n_points;
+    const int32_t* row = job.hit_row + (size_t)t * job.n_points;
+    for (int i = threadIdx.x; i < job.n_points; i += kBlock) {
+        const int r = row[i] + y, c = col[i] + x;
+        uint32_t v = 0;
+        if (r >= 0 && r < job.rows && c >= 0 && c < job.cols)
+            v = job.cells[(size_t)r * job.pitch + c];
+        sm_tp[i] = job.lut[v];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < job.n_points; ++i)
+            sum += sm_tp[i];
+        job.tie_score[blockIdx.x] = sum / (double)job.n_points;
+    }
+}
+
+/* Pick among the tied candidates: highest f64 score, then first in traversal
+ * order (the strict `<` update of scan_matcher_correlative.cpp:358). */
+__global__ void k_tie_pick(TieJob job)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    csm_result* out = reinterpret_cast<csm_result*>(job.out);
+    const uint32_t n = min(*job.tie_count, job.tie_cap);
+    if (n == 0)
+        return;
+    double best = job.tie_score[0];
+    unsigned long long brank = job.tie_list[0];
+    uint32_t same = 1;
+    for (uint32_t i = 1; i < n; ++i) {
+        const double s = job.tie_score[i];
+        const unsigned long long r = job.tie_list[i];
+        if (s > best) {
+            best = s;
+            brank = r;
+            same = 1;
+        } else if (s == best) {
+            ++same;
+            if (r < brank)
+                brank = r;
+        }
+    }
+    const int L = job.rank_l;
+    const int nxc = job.nx / L, nyc = job.ny / L;
+    unsigned long long q = brank;
+    const int fy = (int)(q % L); q /= L;
+    const int fx = (int)(q % L); q /= L;
+    const int yc = (int)(q % nyc); q /= nyc;
+    const int xc = (int)(q % nxc); q /= nxc;
+    const int t = (int)q;
+    csm_result r = *out;
+    r.flags |= CSM_FLAG_KEY_TIE | (same > 1 ? CSM_FLAG_F64_TIE : 0u);
+    if (*job.tie_count > job.tie_cap)
+        r.flags |= CSM_FLAG_EDGE_BAND;   /* overflow: let the literal path decide */
+    r.tie_count = *job.tie_count;
+    if (best > job.score_thr) {
+        r.found = 1;
+        r.best_x = job.x_lo + xc * L + fx;
+        r.best_y = job.y_lo + yc * L + fy;
+        r.best_theta = t - job.win_theta;
+        r.score = best;
+    }
+    *out = r;
+}
+
+/* The reference's sweep, literally, over precomputed exact scores. One
+ * wave64: lanes test 64 coarse nodes at a time against the running maximum;
+ * a passing node is expanded (its L*L fine scores, first strict maximum) and
+ * the remaining lanes are re-tested against the new maximum. */
+__global__ __launch_bounds__(64) void k_csm_literal_scan(LiteralJob job)
+{
+    const int lane = threadIdx.x;
+    const long per_t = (long)job.nxc * job.nyc;
+    const long n_nodes = per_t * job.n_theta;
+    const int L = job.L;
+    const int ny = job.nyc * L, nx = job.nxc * L;
+    double m = job.score_thr;
+    long best_node = -1;
+    int best_f = 0;
+    for (long base = 0; base < n_nodes; base += 64) {
+        const long i = base + lane;
+        double c = 0.0;
+        bool kok = false;
+        if (i < n_nodes) {
+            c = job.coarse_score[i];
+            kok = (int)job.coarse_k[i] >= job.min_known;
+        }
+        int from = 0;
+        while (true) {
+            const bool pass = lane >= from && kok && c > m;
+            const unsigned long long mask = __ballot(pass);
+            if (mask == 0)
+                break;
+            const int first = __ffsll((long long)mask) - 1;
+            const long node = base + first;
+            const int t = (int)(node / per_t);
+            const int xc = (int)((node % per_t) / job.nyc);
+            const int yc = (int)(node % job.nyc);
+            /* expand: lanes over the L*L fine candidates in (fx, fy) order */
+            double fbest = m;
+            int farg = -1;
+            for (int f0 = 0; f0 < L * L; f0 += 64) {
+                const int f = f0 + lane;
+                double s = -1.0;
+                if (f < L * L) {
+                    const int fx = f / L, fy = f % L;
+                    s = job.fine_score[((size_t)t * nx + xc * L + fx) * ny + yc * L + fy];
+                }
+                /* wave arg-max: greatest score, smallest index */
+                double bs = s;
+                int bi = f < L * L ? f : 0x7fffffff;
+                for (int sh = 32; sh >= 1; sh >>= 1) {
+                    const double os = __shfl_xor(bs, sh, 64);
+                    const int oi = __shfl_xor(bi, sh, 64);
+                    if (os > bs || (os == bs && oi < bi)) {
+                        bs = os;
+                        bi = oi;
+                    }
+                }
+                if (bs > fbest) {
+                    fbest = bs;
+                    farg = bi;
+                }
+            }
+            if (farg >= 0) {
+                m = fbest;
+                best_node = node;
+                best_f = farg;
+            }
+            from = first + 1;
+        }
+    }
+    if (lane == 0) {
+        csm_result* out = reinterpret_cast<csm_result*>(job.out);
+        csm_result r = *out;
+        r.flags |= CSM_FLAG_LITERAL;
+        if (best_node >= 0) {
+            const int t = (int)(best_node / per_t);
+            const int xc = (int)((best_node % per_t) / job.nyc);
+            const int yc = (int)(best_node % job.nyc);
+            r.found = 1;
+            r.best_x = job.x_lo + xc * L + best_f / L;
+            r.best_y = job.y_lo + yc * L + best_f % L;
+            r.best_theta = t - job.win_theta;
+            r.score = m;
+        } else {
+            r.found = 0;
+            r.best_x = job.x_lo;
+            r.best_y = job.y_lo;
+            r.best_theta = -job.win_theta;
+            r.score = job.score_thr;
+        }
+        *out = r;
+    }
+}
+
 /* ------------------------------------------------------------------ batch */
 __global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
 {
@@ -524,13 +752,6 @@ __global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
 __global__ __launch_bounds__(kBlock) void k_finalize_batch(const FinalJob* jobs)
 {
     k_finalize_body(jobs[blockIdx.x]);
-}
-
-/* PositionToIndex on device, IEEE double, no contraction: bit-identical to
- * src/grid_map_new/grid_map_geometry.cpp:113-122 */
-__device__ __forceinline__ int cell_index(double pos, double off, double res)
-{
-    return (int)floor((pos - off) / res);
 }
 
 /* Does floor((hit - off) / res) equal `expect`? Cheap certified test first

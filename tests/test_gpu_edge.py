@@ -1,0 +1,135 @@
+"""GPU parity on the inputs that break a naive parallel arg-max: integer-key
+ties, coarse nodes that fail to bound their fine candidates (negative edge
+band), cell-edge-aligned geometry (branch-and-bound per-node projection),
+nothing found, scans off the map, ragged sizes. The checker is always the
+LITERAL sequential restatement (oracle.csm / oracle.bnb)."""
+import math
+
+import numpy as np
+import pytest
+
+from csm_hip import _lib as L
+from csm_hip import api, synth
+
+pytestmark = pytest.mark.gpu
+
+stats = {"tie": 0, "band": 0, "delta": 0, "literal": 0, "band_differs": 0}
+
+
+def _check_csm(ctx, oracle, case, rx, ry, rt, Lr, score_thr=0.0, known_thr=0.0, map_id=50):
+    m = api.ScanMatcherCorrelativeHIP("edge", Lr, rx, ry, rt, ctx=ctx)
+    out = m.optimize_pose(case["grid"], case["geom"], case["angles"], case["ranges"],
+                          case["rel_pose"], case["init_pose"], score_threshold=score_thr,
+                          known_rate_threshold=known_thr)
+    lit = oracle.csm(case, rx, ry, rt, Lr, score_thr, known_thr)
+    raw = out["raw"]
+    assert out["pose_found"] == lit["found"], (raw, lit)
+    assert (raw["best_x"], raw["best_y"], raw["best_theta"]) == (lit["bestX"], lit["bestY"], lit["bestT"]), (raw, lit)
+    assert raw["score"] == lit["scoreMax"]
+    assert out["estimated_pose"] == lit["estimatedPose"]
+    return raw, lit
+
+
+@pytest.mark.parametrize("seed,levels", [(40, 2), (41, 3), (42, 4), (43, 8), (44, 2), (45, 3)])
+def test_csm_integer_key_ties(gpu_ctx, oracle, seed, levels):
+    case = synth.csm_case(seed, levels=levels, interior_unknown=0.0)
+    raw, _ = _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), 4)
+    stats["tie"] += bool(raw["flags"] & L.FLAG_KEY_TIE)
+
+
+@pytest.mark.parametrize("seed,Lr", [(50, 4), (51, 4), (52, 5), (53, 8), (54, 3), (55, 4), (56, 2), (57, 6)])
+def test_csm_negative_edge_band(gpu_ctx, oracle, seed, Lr):
+    case = synth.csm_case(seed, rows=256, cols=288, origin="low_edge", half_x=5.2, half_y=4.4,
+                          init_error=(0.23, 0.19, 0.03))
+    raw, lit = _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), Lr)
+    cf = oracle.csm_closed_form(case, 1.0, 1.0, math.radians(10), Lr)
+    stats["band"] += bool(raw["flags"] & L.FLAG_EDGE_BAND)
+    stats["literal"] += bool(raw["flags"] & L.FLAG_LITERAL)
+    stats["band_differs"] += (cf["bestX"], cf["bestY"], cf["bestT"]) != (lit["bestX"], lit["bestY"], lit["bestT"])
+
+
+def test_csm_thresholds_and_not_found(gpu_ctx, oracle):
+    case = synth.csm_case(60)
+    raw, lit = _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), 4, 0.95, 0.0)
+    assert lit["found"] == 0 and raw["found"] == 0
+    _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), 4, 0.2, 0.9)
+    _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), 4, 0.1, 0.99)
+    _check_csm(gpu_ctx, oracle, case, 0.5, 1.5, math.radians(4), 5, 0.3, 0.5)
+
+
+def test_csm_scan_off_the_map(gpu_ctx, oracle):
+    case = synth.csm_case(61)
+    case["init_pose"] = (40.0, -35.0, 0.3)
+    raw, lit = _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), 4)
+    assert raw["found"] == 0
+
+
+@pytest.mark.parametrize("n_beams,rows,cols,Lr", [(37, 112, 96, 3), (1, 64, 64, 2), (513, 176, 240, 7),
+                                                   (2049, 128, 128, 4)])
+def test_csm_ragged_sizes(gpu_ctx, oracle, n_beams, rows, cols, Lr):
+    case = synth.csm_case(62, rows=rows, cols=cols, n_beams=n_beams, max_range=2.2,
+                          half_x=cols * 0.05 * 0.3, half_y=rows * 0.05 * 0.3, n_boxes=1,
+                          init_error=(0.06, -0.04, 0.01))
+    _check_csm(gpu_ctx, oracle, case, 0.6, 0.4, math.radians(6), Lr)
+
+
+def _check_bnb(ctx, oracle, cases, H, thr, rng=(2.5, 2.5, 0.5), base_id=3000):
+    qs = []
+    for i, c in enumerate(cases):
+        ctx.upload_grid(base_id + i, c["grid"])
+        qs.append(dict(map_id=base_id + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+                       rel_pose=c["rel_pose"], init_pose=c["init_pose"]))
+    outs = ctx.bnb_match_batch(qs, rng[0], rng[1], rng[2], H, thr[0], thr[1])
+    for c, o in zip(cases, outs):
+        want = oracle.bnb(c, rng[0], rng[1], rng[2], H, thr[0], thr[1])
+        raw = o["raw"]
+        assert o["pose_found"] == want["found"], (raw, want)
+        assert (raw["best_x"], raw["best_y"], raw["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"]), (raw, want)
+        assert raw["score"] == want["scoreMax"]
+        assert o["estimated_pose"] == want["estimatedPose"]
+        stats["delta"] += bool(raw["flags"] & L.FLAG_PROJ_DELTA)
+        stats["tie"] += bool(raw["flags"] & L.FLAG_KEY_TIE)
+        stats["band"] += bool(raw["flags"] & L.FLAG_EDGE_BAND)
+        stats["literal"] += bool(raw["flags"] & L.FLAG_LITERAL)
+    for i in range(len(cases)):
+        ctx.release_grid(base_id + i)
+    return outs
+
+
+def test_bnb_ties_on_quantised_maps(gpu_ctx, oracle):
+    cases = [synth.csm_case(70 + i, levels=lv, interior_unknown=0.0, init_error=(0.3, 0.2, 0.04))
+             for i, lv in enumerate([2, 3, 4, 2])]
+    _check_bnb(gpu_ctx, oracle, cases, 2, (0.3, 0.5))
+
+
+def test_bnb_negative_edge_band(gpu_ctx, oracle):
+    cases = [synth.csm_case(80 + i, rows=256, cols=288, origin="low_edge", half_x=5.2, half_y=4.4,
+                            init_error=(0.23, 0.19, 0.03)) for i in range(4)]
+    _check_bnb(gpu_ctx, oracle, cases, 3, (0.3, 0.5), rng=(1.5, 1.5, 0.3))
+
+
+def test_bnb_cell_edge_aligned_projection(gpu_ctx, oracle):
+    """Offsets, walls and poses on exact multiples of the resolution: hit points
+    sit on cell edges, where sensor + x*step + r*cos and (sensor + r*cos) + x
+    can floor differently (scan_matcher_branch_bound.cpp:156-176)."""
+    cases = []
+    for i in range(4):
+        c = synth.csm_case(90 + i, origin="aligned", truth=(0.0, 0.0, 0.0),
+                           init_error=(0.25, -0.15, 0.0))
+        cases.append(c)
+    c = synth.csm_case(95, origin="aligned", truth=(0.5, -0.25, math.pi / 2),
+                       init_error=(0.0, 0.0, 0.0))
+    cases.append(c)
+    _check_bnb(gpu_ctx, oracle, cases, 2, (0.3, 0.5))
+
+
+def test_csm_cell_edge_aligned(gpu_ctx, oracle):
+    case = synth.csm_case(96, origin="aligned", truth=(0.0, 0.0, 0.0), init_error=(0.25, -0.15, 0.0))
+    _check_csm(gpu_ctx, oracle, case, 1.0, 1.0, math.radians(10), 4)
+
+
+def test_zz_edge_paths_were_exercised():
+    """The inputs above must actually reach the exact paths."""
+    print("edge-path statistics:", stats)
+    assert stats["tie"] > 0
+    assert stats["literal"] > 0
