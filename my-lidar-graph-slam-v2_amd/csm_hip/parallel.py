@@ -1,0 +1,121 @@
+"""Multi-GPU loop detection: one process per GPU, queries sharded in contiguous
+blocks (the reference's own two-core split is first half / second half,
+src/my_lidar_graph_slam/mapping/loop_detector_fpga_parallel.cpp:42-46), one
+all-gather of the fixed-size best records (48 B per query) where the reference
+concatenates the per-core result vectors (loop_detector_fpga_parallel.cpp:53-56).
+
+torch.distributed is only the transport ("nccl" = RCCL over xGMI on the GPU
+node, "gloo" in the CPU tests); the records are plain bytes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+RECORD_BYTES = C.sizeof(L.Result)   # 48
+
+
+def shard_bounds(n_queries, rank, world):
+    """Contiguous block of rank `rank`: sizes differ by at most one, earlier
+    ranks take the larger blocks."""
+    base, rem = divmod(n_queries, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def records_to_bytes(raw_results):
+    """list of dict (api.result_to_dict) -> uint8 [n, 48] in csm_result layout."""
+    arr = (L.Result * len(raw_results))()
+    for i, r in enumerate(raw_results):
+        a = arr[i]
+        a.found, a.best_x, a.best_y, a.best_theta = r["found"], r["best_x"], r["best_y"], r["best_theta"]
+        a.key, a.sum_values, a.known = r["key"], r["sum_values"], r["known"]
+        a.tie_count, a.flags, a.score = r["tie_count"], r["flags"], r["score"]
+    return np.frombuffer(bytes(arr), dtype=np.uint8).reshape(len(raw_results), RECORD_BYTES).copy()
+
+
+def bytes_to_records(buf):
+    buf = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1, RECORD_BYTES)
+    arr = (L.Result * buf.shape[0]).from_buffer_copy(buf.tobytes())
+    return [dict(found=int(a.found), best_x=int(a.best_x), best_y=int(a.best_y),
+                 best_theta=int(a.best_theta), key=int(a.key), sum_values=int(a.sum_values),
+                 known=int(a.known), tie_count=int(a.tie_count), flags=int(a.flags),
+                 score=float(a.score)) for a in arr]
+
+
+def allgather_records(local, n_queries, group=None, device=None):
+    """All-gather the per-rank record blocks into query order.
+
+    local: uint8 [m, 48] for this rank's shard_bounds block. Blocks are padded
+    to the largest block so a single fixed-size all_gather suffices."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(n_queries, rank, world)
+    assert local.shape == (hi - lo, RECORD_BYTES), (local.shape, hi - lo)
+    max_block = -(-n_queries // world)
+    send = torch.zeros(max_block * RECORD_BYTES, dtype=torch.uint8, device=device)
+    if hi > lo:
+        send[:(hi - lo) * RECORD_BYTES] = torch.from_numpy(local.reshape(-1)).to(send.device)
+    recv = torch.zeros(world * max_block * RECORD_BYTES, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.cpu().numpy().reshape(world, max_block, RECORD_BYTES)
+    out = np.zeros((n_queries, RECORD_BYTES), np.uint8)
+    for r in range(world):
+        a, b = shard_bounds(n_queries, r, world)
+        out[a:b] = recv[r, :b - a]
+    return out
+
+
+class LoopDetectorBranchBoundHIP:
+    """Search part of LoopDetectorBranchBound::Detect
+    (src/my_lidar_graph_slam/mapping/loop_detector_branch_bound.cpp:59-156),
+    constructor arguments as in src/my_lidar_graph_slam/loop_detector_factory.cpp:161-183.
+
+    `scorer(queries) -> list of raw result dicts` defaults to the HIP batch; the
+    CPU (gloo) tests pass a stand-in so that the sharding and gather logic can
+    run without a GPU."""
+
+    def __init__(self, name, ctx, range_x, range_y, range_theta, node_height_max,
+                 score_threshold, known_rate_threshold, group=None, scorer=None, device=None):
+        self.name = name
+        self.ctx = ctx
+        self.params = (range_x, range_y, range_theta, node_height_max)
+        self.score_threshold = score_threshold
+        self.known_rate_threshold = known_rate_threshold
+        self.group = group
+        self.device = device
+        self._scorer = scorer or self._hip_scorer
+
+    def _hip_scorer(self, queries):
+        rx, ry, rt, H = self.params
+        outs = self.ctx.bnb_match_batch(queries, rx, ry, rt, H, self.score_threshold,
+                                        self.known_rate_threshold)
+        return [o["raw"] for o in outs]
+
+    def detect(self, queries, grids=None):
+        """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose);
+        grids: optional {map_id: uint16 grid} uploaded once per id (the
+        mPrecompMaps cache of loop_detector_branch_bound.hpp:98).
+        Returns (all raw records in query order, indices of the found ones)."""
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size(self.group) if distributed else 1
+        rank = dist.get_rank(self.group) if distributed else 0
+        n = len(queries)
+        lo, hi = shard_bounds(n, rank, world)
+        mine = queries[lo:hi]
+        if grids is not None and self.ctx is not None:
+            for q in mine:
+                if not self.ctx.has_grid(q["map_id"]):
+                    self.ctx.upload_grid(q["map_id"], grids[q["map_id"]])
+        local = records_to_bytes(self._scorer(mine)) if mine else np.zeros((0, RECORD_BYTES), np.uint8)
+        if distributed and world > 1:
+            allrec = allgather_records(local, n, self.group, self.device)
+        else:
+            allrec = local
+        records = bytes_to_records(allrec)
+        found = [i for i, r in enumerate(records) if r["found"]]
+        return records, found
