@@ -176,6 +176,11 @@ struct Plan {
 };
 
 const int kRChoices[] = { 4, 5, 6, 7, 8 };
+
+int pick_lstride(int need)
+{
+    return need <= 96 ? 96 : need <= 128 ? 128 : need <= 160 ? 160 : need <= 192 ? 192 : 0;
+}
 const int kCoarseSlices = 8;
 
 void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* R,
@@ -188,6 +193,8 @@ void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* 
     int g = kBlock / *cbx;
     if (g < 1)
         g = 1;
+    /* the staged region may not exceed kMaxRegionRows rows */
+    const int max_cby = kMaxRegionRows - kTile + 1;
     if (fixed_r1) {
         *R = 1;
         if (g > ny)
@@ -200,6 +207,7 @@ void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* 
     long best_cost = -1;
     for (int r : kRChoices) {
         int gg = std::min(g, ceil_div(ny, r));
+        gg = std::max(1, std::min(gg, max_cby / r));
         const int nby = ceil_div(ny, gg * r);
         /* cost ~ lane-rows issued (idle lanes still occupy the SIMD) */
         const long cost = (long)nby * r * 1000 / 1 + (long)(kBlock - gg * *cbx);
@@ -232,22 +240,22 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     p->y_hi = p->y_lo + p->ny - 1;
     plan_blocks(p->nx, p->ny, 1, &p->cbx, &p->groups, &p->R, &p->ncbx, &p->ncby, false);
     const int need = kTile + 7 + p->cbx;
-    p->lstride = need <= 64 ? 64 : need <= 96 ? 96 : need <= 128 ? 128 : 160;
-    if (need > 160)
+    p->lstride = pick_lstride(need);
+    if (!p->lstride)
         return fail(ctx, CSM_EINVAL, "internal: candidate block too wide");
     /* coarse pass: candidates L cells apart, must fit the same LDS pitch */
     p->c_cbx = std::min(p->nxc, (p->lstride - kTile - 8) / p->L + 1);
     p->c_ncbx = ceil_div(p->nxc, p->c_cbx);
     p->c_cbx = ceil_div(p->nxc, p->c_ncbx);
     int cg = std::max(1, kBlock / p->c_cbx);
-    cg = std::min(cg, 64 / p->L + 1);
+    cg = std::min(cg, (kMaxRegionRows - kTile) / p->L + 1);
     cg = std::min(cg, p->nyc);
     p->c_groups = cg;
     p->c_ncby = ceil_div(p->nyc, cg);
     p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
     p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi, kTile);
-    p->max_tiles = std::min(p->n, p->tiles_x * p->tiles_y);
-    const size_t bin_lds = (2 * (size_t)p->tiles_x * p->tiles_y + 2 * kBlock) * 4;
+    p->max_tiles = std::min(p->n, p->tiles_x * p->tiles_y) + p->n / kPbMax + 1;
+    const size_t bin_lds = (6 * (size_t)p->tiles_x * p->tiles_y + 2 * kBlock) * 4;
     if (bin_lds > 160 * 1024)
         return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
     return CSM_OK;
@@ -287,23 +295,23 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, int lstride, int R, bool str
 {
     const dim3 grid(ncb, n_theta, n_slices);
     const int stride = strided ? job.stride : 1;
-    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 2;
+    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 4 + kPbMax * 4;
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
     if (strided) {
         switch (lstride) {
-        case 64: LAUNCH_SCORE(64, 1, true); break;
         case 96: LAUNCH_SCORE(96, 1, true); break;
         case 128: LAUNCH_SCORE(128, 1, true); break;
         case 160: LAUNCH_SCORE(160, 1, true); break;
+        case 192: LAUNCH_SCORE(192, 1, true); break;
         default: return fail(ctx, CSM_EINVAL, "internal: lstride");
         }
     } else {
         switch (lstride) {
-        case 64: DISPATCH_R(64); break;
         case 96: DISPATCH_R(96); break;
         case 128: DISPATCH_R(128); break;
         case 160: DISPATCH_R(160); break;
+        case 192: DISPATCH_R(192); break;
         default: return fail(ctx, CSM_EINVAL, "internal: lstride");
         }
     }
@@ -380,7 +388,7 @@ struct WindowOutputs {
 /* The CSM pipeline on device-resident inputs; asynchronous. */
 int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
                const int32_t* hit_col_dev, const int32_t* hit_row_dev,
-               csm_result* out_dev, const WindowOutputs* dumps)
+               csm_result* out_dev, const WindowOutputs* dumps, bool force_coarse = false)
 {
     if (w->coarse_level < 0 || w->coarse_level >= (int)g.levels.size())
         return fail(ctx, CSM_ENOENT, "coarse level %d not built", w->coarse_level);
@@ -428,7 +436,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         bj.band_ny[0] = p.nyc;
     }
     {
-        const size_t lds = (2 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4;
+        const size_t lds = (6 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4;
         if ((rc = set_lds(ctx, k_bin, lds))) return rc;
         ScopedTimer tm(ctx, "bin");
         hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBlock), lds, ctx->stream, bj);
@@ -460,6 +468,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         cj.acc_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
         cj.acc_k = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
         cj.rank_l = 1;
+        cj.skip_unless_band = w->min_known <= 1 && !force_coarse;
         const size_t nodes = nt * p.nxc * p.nyc;
         ScopedTimer tm(ctx, "score_coarse");
         HIP_TRY(ctx, hipMemsetAsync(cj.acc_s, 0, nodes * 4, ctx->stream));
@@ -489,6 +498,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         fj.elig[0].div = p.L;
         fj.elig[0].nxc = p.nxc;
         fj.elig[0].nyc = p.nyc;
+        fj.elig_only_if_band = w->min_known <= 1 && !force_coarse;
     } else {
         fj.check_own_known = 1;
     }
@@ -1034,7 +1044,8 @@ int csm_score_window_dump(csm_ctx* ctx, uint64_t map_id, const csm_window* w, co
         if ((rc = ensure(ctx, ctx->dump_k, nc * 2))) return rc;
         dumps.dump_k = reinterpret_cast<uint16_t*>(ctx->dump_k.p);
     }
-    rc = run_window(ctx, *g, w, p, col_dev, row_dev, res_dev, (dump_s || dump_k) ? &dumps : nullptr);
+    rc = run_window(ctx, *g, w, p, col_dev, row_dev, res_dev, (dump_s || dump_k) ? &dumps : nullptr,
+                    dump_coarse_k != nullptr);
     if (rc)
         return rc;
     if ((rc = resolve_window(ctx, *g, w, p, col_dev, row_dev, res_dev)))
@@ -1156,23 +1167,23 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, int l
                        int n_slices)
 {
     const dim3 grid(ncb, n_theta_max, n_jobs * n_slices);
-    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 2;
+    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 4 + kPbMax * 4;
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
     if (strided) {
         switch (lstride) {
-        case 64: LAUNCH_SCORE_B(64, 1, true); break;
         case 96: LAUNCH_SCORE_B(96, 1, true); break;
         case 128: LAUNCH_SCORE_B(128, 1, true); break;
         case 160: LAUNCH_SCORE_B(160, 1, true); break;
+        case 192: LAUNCH_SCORE_B(192, 1, true); break;
         default: return fail(ctx, CSM_EINVAL, "internal: lstride");
         }
     } else {
         switch (lstride) {
-        case 64: DISPATCH_R_B(64); break;
         case 96: DISPATCH_R_B(96); break;
         case 128: DISPATCH_R_B(128); break;
         case 160: DISPATCH_R_B(160); break;
+        case 192: DISPATCH_R_B(192); break;
         default: return fail(ctx, CSM_EINVAL, "internal: lstride");
         }
     }
@@ -1337,8 +1348,8 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         p.ny = ceil_div(2 * p.win_y + 1, big) * big;
         p.tiles_x = ceil_div(p.grid->cols + p.win_x + (-p.win_x + p.nx - 1), kTile);
         p.tiles_y = ceil_div(p.grid->rows + p.win_y + (-p.win_y + p.ny - 1), kTile);
-        p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y);
-        bin_lds = std::max(bin_lds, (2 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4);
+        p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y) + p.n / kPbMax + 1;
+        bin_lds = std::max(bin_lds, (6 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4);
         p.hit_off = hit_total;
         p.tile_off = tile_total;
         p.theta_off = theta_total;
@@ -1384,10 +1395,9 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     /* ---- launch geometry shared by the group ---- */
     int cbx, groups, R, ncbx, ncby;
     plan_blocks(nx, ny, 1, &cbx, &groups, &R, &ncbx, &ncby, false);
-    const int need = kTile + 7 + cbx;
-    if (need > 160)
+    const int lstride = pick_lstride(kTile + 7 + cbx);
+    if (!lstride)
         return fail(ctx, CSM_EINVAL, "internal: candidate block too wide");
-    const int lstride = need <= 64 ? 64 : need <= 96 ? 96 : need <= 128 ? 128 : 160;
     const int ncb = ncbx * ncby;
 
     /* ---- workspaces ---- */
@@ -1599,7 +1609,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         const int c_ncbx = ceil_div(nxh, c_cbx);
         c_cbx = ceil_div(nxh, c_ncbx);
         int cg = std::max(1, kBlock / c_cbx);
-        cg = std::min(cg, 64 / st + 1);
+        cg = std::min(cg, (kMaxRegionRows - kTile) / st + 1);
         cg = std::min(cg, nyh);
         const int c_ncby = ceil_div(nyh, cg);
         /* keep >= ~2k workgroups in flight: split the tile list when the

@@ -7,7 +7,9 @@
 
 namespace csm {
 
-constexpr int kTile = 32;        /* endpoint tile edge, cells */
+constexpr int kTile = 64;        /* endpoint tile edge, cells */
+constexpr int kMaxRegionRows = 96; /* LDS region rows a workgroup may stage */
+constexpr int kPbMax = 1024;       /* beams per TileRec: k_bin splits fuller tiles */
 constexpr int kBlock = 256;      /* threads per workgroup (4 wave64) */
 constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
 /* internal flag bit (never returned): some beam can reach the negative edge
@@ -16,9 +18,12 @@ constexpr uint32_t kFlagBandTouch = 1u << 16;
 
 /* One non-empty endpoint tile of one theta slice. */
 struct TileRec {
-    int32_t  r0, c0;     /* grid row / col of the tile's first cell */
+    int32_t  r0, c0;     /* grid row / col of the first cell of the tile's
+                            bounding box around its beams */
     uint32_t start;      /* first beam in the slice's sorted list */
     uint32_t count;
+    int32_t  h, w;       /* bounding box extent, cells (<= kTile) */
+    int32_t  pad[2];
 };
 
 /* Best candidate of one workgroup (or of a reduction of several). */
@@ -86,6 +91,13 @@ struct ScoreJob {
     int32_t min_known;
     int32_t check_own_known;   /* also require the candidate's own K >= min_known */
     int32_t rank_l;            /* L of the traversal rank (1: plain t,x,y order) */
+    /* min_known <= 1 only: when no beam can reach the negative edge band the
+     * coarser level bounds every candidate by construction and passes the
+     * known test whenever the candidate's own K >= 1, so a coarse job with
+     * skip_unless_band exits at once and a fine job with elig_only_if_band
+     * ignores its eligibility levels. */
+    int32_t skip_unless_band;
+    int32_t elig_only_if_band;
     EligLevel elig[kMaxElig];
 };
 

@@ -64,7 +64,11 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int ntile = job.tiles_x * job.tiles_y;
     uint32_t* hist = sm_bin;            /* [ntile] counts, later cursors */
     uint32_t* first = sm_bin + ntile;   /* [ntile] start offsets */
-    uint32_t* part = first + ntile;     /* [2 * kBlock] */
+    uint32_t* bb_rmin = first + ntile;  /* [ntile] beam bounding box inside the tile */
+    uint32_t* bb_rmax = bb_rmin + ntile;
+    uint32_t* bb_cmin = bb_rmax + ntile;
+    uint32_t* bb_cmax = bb_cmin + ntile;
+    uint32_t* part = bb_cmax + ntile;   /* [2 * kBlock] */
     const int t = blockIdx.x;
     if (t >= job.n_theta)
         return;
@@ -73,8 +77,13 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int32_t* col = job.hit_col + (size_t)t * n;
     const int32_t* row = job.hit_row + (size_t)t * n;
 
-    for (int i = tid; i < ntile; i += kBlock)
+    for (int i = tid; i < ntile; i += kBlock) {
         hist[i] = 0;
+        bb_rmin[i] = kTile;
+        bb_cmin[i] = kTile;
+        bb_rmax[i] = 0;
+        bb_cmax[i] = 0;
+    }
     __syncthreads();
 
     const int r_max = job.rows - 1 - job.y_lo;
@@ -83,8 +92,14 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     for (int i = tid; i < n; i += kBlock) {
         const int r = row[i], c = col[i];
         const int rr = r + job.y_hi, cc = c + job.x_hi;
-        if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max)
-            atomicAdd(&hist[(rr / kTile) * job.tiles_x + cc / kTile], 1u);
+        if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
+            const int tile = (rr / kTile) * job.tiles_x + cc / kTile;
+            atomicAdd(&hist[tile], 1u);
+            atomicMin(&bb_rmin[tile], (uint32_t)(rr % kTile));
+            atomicMax(&bb_rmax[tile], (uint32_t)(rr % kTile));
+            atomicMin(&bb_cmin[tile], (uint32_t)(cc % kTile));
+            atomicMax(&bb_cmax[tile], (uint32_t)(cc % kTile));
+        }
         for (int b = 0; b < job.n_band; ++b) {
             const int w = job.band_win[b];
             if (band_index(r + job.y_lo, w, job.band_ny[b]) >= 0 ||
@@ -102,7 +117,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     uint32_t cnt = 0, ne = 0;
     for (int i = lo; i < hi; ++i) {
         cnt += hist[i];
-        ne += hist[i] != 0;
+        ne += (hist[i] + kPbMax - 1) / kPbMax;
     }
     part[tid] = cnt;
     part[kBlock + tid] = ne;
@@ -124,12 +139,15 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     for (int i = lo; i < hi; ++i) {
         const uint32_t c = hist[i];
         first[i] = off;
-        if (c != 0) {
+        for (uint32_t done = 0; done < c; done += kPbMax) {
             TileRec rec;
-            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi;
-            rec.c0 = (i % job.tiles_x) * kTile - job.x_hi;
-            rec.start = off;
-            rec.count = c;
+            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi + (int)bb_rmin[i];
+            rec.c0 = (i % job.tiles_x) * kTile - job.x_hi + (int)bb_cmin[i];
+            rec.start = off + done;
+            rec.count = min(c - done, (uint32_t)kPbMax);
+            rec.h = (int)(bb_rmax[i] - bb_rmin[i]) + 1;
+            rec.w = (int)(bb_cmax[i] - bb_cmin[i]) + 1;
+            rec.pad[0] = rec.pad[1] = 0;
             recs[slot++] = rec;
         }
         off += c;
@@ -145,8 +163,10 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         const int rr = r + job.y_hi, cc = c + job.x_hi;
         if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
             const int ty = rr / kTile, tx = cc / kTile;
-            const uint32_t pos = atomicAdd(&hist[ty * job.tiles_x + tx], 1u);
-            out[pos] = (uint32_t)((rr - ty * kTile) * job.lstride + (cc - tx * kTile));
+            const int tile = ty * job.tiles_x + tx;
+            const uint32_t pos = atomicAdd(&hist[tile], 1u);
+            out[pos] = (uint32_t)((rr - ty * kTile - (int)bb_rmin[tile]) * job.lstride +
+                                  (cc - tx * kTile - (int)bb_cmin[tile]));
         }
     }
 }
@@ -204,59 +224,180 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     if (by * cby >= job.ny)
         return;
 
+    const uint32_t qflags = (job.skip_unless_band || job.elig_only_if_band) ? *job.flags : 0u;
+    if (job.skip_unless_band && !(qflags & kFlagBandTouch))
+        return;
+
     const int dxi = tid % cbx, g = tid / cbx;
     const bool lane_on = g < groups;
     /* first candidate offset of this block, in cells */
     const int x0 = job.x_lo + bx * cbx * stride;
     const int y0 = job.y_lo + by * cby * stride;
-    const int region_rows = kTile + (cby - 1) * stride;
+    /* LDS: one region of max_rows x LSTRIDE expanded cells (u32), then the
+     * beam offsets of the tile (kPbMax words) */
+    const int max_rows = kTile + (cby - 1) * stride;
+    uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
+    uint32_t* lpb = sm_cells + max_rows * LSTRIDE;
     /* lane base inside the region (cells) */
     const int tb = lane_on ? (g * R * stride) * LSTRIDE + dxi * stride : 0;
     const int row_step = stride * LSTRIDE;
+    const int lane = tid & 63;
 
-    uint32_t S[R], K[R];
+    /* acc packs (known count << 24) + (sum of values) of at most 255 beams;
+     * S, K are the exact totals */
+    uint32_t S[R], K[R], acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         S[r] = 0;
         K[r] = 0;
+        acc[r] = 0;
     }
+    int pending = 0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S[r] += acc[r] & 0xffffffu;
+            K[r] += acc[r] >> 24;
+            acc[r] = 0;
+        }
+        pending = 0;
+    };
 
+    const int grid_rows = job.rows, grid_pitch = job.pitch;
+    const uint16_t* __restrict__ cells = job.cells;
     const int ntiles = job.n_tiles[t];
     const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
-    const uint32_t* pbs = job.sorted_pb + (size_t)t * job.n_points;
-    constexpr int kChunks = LSTRIDE / 8;
+    const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)t * job.n_points;
+    /* chunks (8 cells, 16 B of the uint16 grid) one lane may have to fetch per tile */
+    constexpr int kMaxCh = (kMaxRegionRows * (LSTRIDE / 8) + kBlock - 1) / kBlock;
+    constexpr int kPbRegs = kPbMax / kBlock;
 
-    for (int ti = slice; ti < ntiles; ti += n_slices) {
-        const TileRec rec = recs[ti];
-        const int cs = (rec.c0 + x0) & ~7;          /* 16-byte aligned first col */
-        const int a = (rec.c0 + x0) - cs;           /* 0..7 */
-        const int gr0 = rec.r0 + y0;
-
-        __syncthreads();                            /* previous tile consumed */
-        for (int idx = tid; idx < region_rows * kChunks; idx += kBlock) {
-            const int lr = idx / kChunks, ch = idx - lr * kChunks;
-            const int gr = gr0 + lr, gc = cs + ch * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gr >= 0 && gr < job.rows && gc >= 0 && gc < job.pitch)
-                v = *reinterpret_cast<const uint4*>(job.cells + (size_t)gr * job.pitch + gc);
-            *reinterpret_cast<uint4*>(sm_tile + lr * LSTRIDE + ch * 8) = v;
-        }
-        __syncthreads();
-
-        const uint32_t* pb = pbs + rec.start;
-        const int cnt = (int)rec.count;
-        const uint16_t* base = sm_tile + tb + a;
-#pragma unroll 4
-        for (int b = 0; b < cnt; ++b) {
-            const uint16_t* p = base + pb[b];
+    /* Software pipeline: the global loads of tile i+1 (cells and beam offsets)
+     * are in flight in registers while the lanes gather tile i out of LDS;
+     * nothing in the gather loop waits on vector or scalar memory. Only the
+     * bounding box of the tile's beams (+ the block's candidate span) is
+     * staged. Cells are expanded on the way into LDS to v + (v != 0) << 24,
+     * so that one 32-bit add per gather accumulates both the value sum and the
+     * known count. */
+    uint4 pre[kMaxCh];
+    uint32_t pre_pb[kPbRegs];
+    int nch = 1, total = 0;
+    int lr0 = 0, ch0 = 0, dq = 0, dr = 0;   /* (row, chunk) of this lane's first chunk; step per k */
+    TileRec rec;
+    auto fetch = [&](const TileRec& tr) {
+        const int cs = (tr.c0 + x0) & ~7;           /* 16-byte aligned first col */
+        const int a = (tr.c0 + x0) - cs;            /* 0..7 */
+        const int nrows = tr.h + (cby - 1) * stride;
+        nch = (a + tr.w + (cbx - 1) * stride + 7) >> 3;
+        total = nrows * nch;
+        const int gr0 = tr.r0 + y0;
+        /* chunk idx = tid + k*kBlock -> (row, chunk-in-row), stepped without
+         * a division per chunk */
+        lr0 = tid / nch;
+        ch0 = tid - lr0 * nch;
+        dq = kBlock / nch;
+        dr = kBlock - dq * nch;
+        int lr = lr0, ch = ch0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t v = STRIDED ? p[r * row_step] : p[r * LSTRIDE];
-                S[r] += v;
-                K[r] += v != 0 ? 1u : 0u;
+        for (int k = 0; k < kMaxCh; ++k) {
+            const int idx = tid + k * kBlock;
+            const int gr = gr0 + lr, gc = cs + ch * 8;
+            const bool ok = idx < total && gr >= 0 && gr < grid_rows && gc >= 0 && gc < grid_pitch;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok)
+                v = *reinterpret_cast<const uint4*>(cells + (size_t)gr * grid_pitch + gc);
+            pre[k] = v;
+            lr += dq;
+            ch += dr;
+            if (ch >= nch) {
+                ch -= nch;
+                ++lr;
             }
         }
+#pragma unroll
+        for (int q = 0; q < kPbRegs; ++q) {
+            const uint32_t bi = tid + q * kBlock;
+            pre_pb[q] = bi < tr.count ? pbs[tr.start + bi] : 0u;
+        }
+    };
+    auto expand = [](uint32_t v) { return v + (min(v, 1u) << 24); };
+    int ti = slice;
+    if (ti < ntiles) {
+        rec = recs[ti];
+        fetch(rec);
     }
+    for (; ti < ntiles; ti += n_slices) {
+        __syncthreads();                             /* previous tile consumed */
+        {
+            int lr = lr0, ch = ch0;
+#pragma unroll
+            for (int k = 0; k < kMaxCh; ++k) {
+                if (tid + k * kBlock < total) {
+                    const uint4 w = pre[k];
+                    uint4 lo4, hi4;
+                    lo4.x = expand(w.x & 0xffffu);
+                    lo4.y = expand(w.x >> 16);
+                    lo4.z = expand(w.y & 0xffffu);
+                    lo4.w = expand(w.y >> 16);
+                    hi4.x = expand(w.z & 0xffffu);
+                    hi4.y = expand(w.z >> 16);
+                    hi4.z = expand(w.w & 0xffffu);
+                    hi4.w = expand(w.w >> 16);
+                    uint4* dst = reinterpret_cast<uint4*>(sm_cells + lr * LSTRIDE + ch * 8);
+                    dst[0] = lo4;
+                    dst[1] = hi4;
+                }
+                lr += dq;
+                ch += dr;
+                if (ch >= nch) {
+                    ch -= nch;
+                    ++lr;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kPbRegs; ++q)
+            lpb[tid + q * kBlock] = pre_pb[q];
+        __syncthreads();
+        const TileRec cur = rec;
+        if (ti + n_slices < ntiles) {
+            rec = recs[ti + n_slices];
+            fetch(rec);
+        }
+        const int a = (cur.c0 + x0) & 7;
+        const int cnt = (int)cur.count;
+        const uint32_t* base = sm_cells + tb + a;
+        auto gather = [&](uint32_t off) {
+            const uint32_t* p = base + off;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                acc[r] += STRIDED ? p[r * row_step] : p[r * LSTRIDE];
+        };
+        /* beam offsets: 64 per LDS read, broadcast with v_readlane */
+        uint32_t pb_cur = lpb[lane];
+        for (int b0 = 0; b0 < cnt; b0 += 64) {
+            const uint32_t pb_nxt = lpb[(b0 + 64 + lane) & (kPbMax - 1)];
+            const int m = min(64, cnt - b0);
+            if (pending + m > 255)
+                flush();
+            pending += m;
+            int j = 0;
+            for (; j + 4 <= m; j += 4) {
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j);
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j + 1);
+                const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j + 2);
+                const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j + 3);
+                gather(o0);
+                gather(o1);
+                gather(o2);
+                gather(o3);
+            }
+            for (; j < m; ++j)
+                gather((uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j));
+            pb_cur = pb_nxt;
+        }
+    }
+    flush();
 
     /* ---- epilogue: dumps, eligibility, arg-max ---- */
     const int xi = bx * cbx + dxi;
@@ -285,11 +426,12 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
             }
             if (!job.block_best && !job.tie_list)
                 continue;
-            bool ok = !job.check_own_known || (int)K[r] >= job.min_known;
+            const bool use_elig = !job.elig_only_if_band || (qflags & kFlagBandTouch);
+            bool ok = !(job.check_own_known || !use_elig) || (int)K[r] >= job.min_known;
             const unsigned long long key =
                 32268ull * K[r] + 499ull * (unsigned long long)S[r];
             bool broken = false;
-            for (int e = 0; e < job.n_elig && ok; ++e) {
+            for (int e = 0; e < job.n_elig && ok && use_elig; ++e) {
                 const EligLevel& el = job.elig[e];
                 const size_t ni =
                     ((size_t)t * el.nxc + xi / el.div) * el.nyc + yi / el.div;
