@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <queue>
@@ -205,7 +206,10 @@ void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* 
     }
     /* pick R (and trim groups) minimising padded candidate rows */
     long best_cost = -1;
+    const char* force = getenv("CSM_FORCE_R");   /* tuning knob */
     for (int r : kRChoices) {
+        if (force && atoi(force) != r)
+            continue;
         int gg = std::min(g, ceil_div(ny, r));
         gg = std::max(1, std::min(gg, max_cby / r));
         const int nby = ceil_div(ny, gg * r);

@@ -1,0 +1,96 @@
+/* adapter_demo.cpp -- drives the C++ adapters of csm_adapters.hpp from a
+ * binary case file written by tests/test_gpu_adapter.py and prints one JSON
+ * line. Built with g++ against libcsm_hip.so; exercises the same entry points a
+ * reference-side ScanMatcher / LoopDetector subclass would.
+ *
+ * case file (little endian):
+ *   int32 mode(0 csm, 1 bnb), rows, cols, n, n_queries, param_i (L or H)
+ *   double res, offX, offY, rangeX, rangeY, rangeT, scoreThr, knownThr
+ *   double rel[3]; double init[3 * n_queries]; double angles[n]; double ranges[n]
+ *   uint16 grid[rows * cols]
+ */
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "csm_adapters.hpp"
+
+using namespace CsmHip;
+
+template <typename T>
+static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
+
+int main(int argc, char** argv)
+{
+    if (argc < 2)
+        return 2;
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f)
+        return 2;
+    int32_t hdr[6];
+    double prm[8], rel[3];
+    if (!rd(f, hdr, 6) || !rd(f, prm, 8) || !rd(f, rel, 3))
+        return 2;
+    const int mode = hdr[0], rows = hdr[1], cols = hdr[2], n = hdr[3], nq = hdr[4], pi = hdr[5];
+    std::vector<double> init(3 * nq), angles(n), ranges(n);
+    std::vector<uint16_t> grid((size_t)rows * cols);
+    if (!rd(f, init.data(), init.size()) || !rd(f, angles.data(), n) || !rd(f, ranges.data(), n) ||
+        !rd(f, grid.data(), grid.size()))
+        return 2;
+    std::fclose(f);
+
+    GridMapView g;
+    g.mValues = grid.data();
+    g.mRows = rows;
+    g.mCols = cols;
+    g.mResolution = prm[0];
+    g.mPosOffsetX = prm[1];
+    g.mPosOffsetY = prm[2];
+    ScanDataView s;
+    s.mAngles = angles.data();
+    s.mRanges = ranges.data();
+    s.mNumOfScans = n;
+    s.mRelativeSensorPose = { rel[0], rel[1], rel[2] };
+
+    if (mode == 0) {
+        auto m = ScanMatcherCorrelativeHIP::Create("demo", pi, prm[3], prm[4], prm[5]);
+        if (!m) {
+            std::printf("{\"error\": \"no device\"}\n");
+            return 3;
+        }
+        ScanMatchingQuery q { g, s, { init[0], init[1], init[2] } };
+        const ScanMatchingSummary r = (prm[6] == 0.0 && prm[7] == 0.0)
+                                          ? m->OptimizePose(q)
+                                          : m->OptimizePose(q, prm[6], prm[7]);
+        std::printf("{\"found\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\", \"win\": [%d, %d, %d]}\n",
+                    r.mPoseFound ? 1 : 0, r.mEstimatedPose.mX, r.mEstimatedPose.mY,
+                    r.mEstimatedPose.mTheta, r.mScoreValue, r.mWinSizeX, r.mWinSizeY, r.mWinSizeTheta);
+        return 0;
+    }
+    auto d = LoopDetectorBranchBoundHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7]);
+    if (!d) {
+        std::printf("{\"error\": \"no device\"}\n");
+        return 3;
+    }
+    g.mId = 42;
+    LoopDetectionQueryVector qs;
+    for (int i = 0; i < nq; ++i) {
+        LoopDetectionQuery q;
+        q.mReferenceLocalMap = g;
+        q.mQueryScanData = s;
+        /* local map node at the origin: the scan node's global pose is its map-local pose */
+        q.mReferenceLocalMapNodeGlobalPose = { 0.0, 0.0, 0.0 };
+        q.mQueryScanNodeGlobalPose = { init[3 * i], init[3 * i + 1], init[3 * i + 2] };
+        q.mQueryScanNodeId = i;
+        qs.push_back(q);
+    }
+    const LoopDetectionResultVector rs = d->Detect(qs);
+    std::printf("{\"results\": [");
+    for (size_t i = 0; i < rs.size(); ++i)
+        std::printf("%s{\"node\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\"}", i ? ", " : "",
+                    rs[i].mScanNodeId, rs[i].mRelativePose.mX, rs[i].mRelativePose.mY,
+                    rs[i].mRelativePose.mTheta, rs[i].mScoreValue);
+    std::printf("]}\n");
+    return 0;
+}

@@ -1,0 +1,344 @@
+/* csm_adapters.hpp -- header-only C++17 host side above the C ABI
+ * (include/csm_hip.h). Mirrors the reference's plugin interfaces for the hot
+ * path with the same names, argument meaning and error behaviour:
+ *
+ *   ScanMatcherCorrelativeHIP   <- ScanMatcherCorrelative
+ *        inc/mapping/scan_matcher_correlative.hpp:53-125, scan_matcher.hpp:89-117
+ *   LoopDetectorBranchBoundHIP  <- LoopDetectorBranchBound (search part)
+ *        inc/mapping/loop_detector_branch_bound.hpp:71-112, loop_detector.hpp:97-116
+ *
+ * The reference headers cannot be included in this image (Eigen3 / Boost are
+ * absent), so the few value types the interfaces use are restated here in
+ * namespace CsmHip. INTEGRATION.md shows the ~40-line glue a maintainer adds
+ * inside the reference tree to derive these from the real
+ * MyLidarGraphSlam::Mapping::ScanMatcher / LoopDetector.
+ *
+ * Error convention: like the reference's Assert() (inc/util.hpp:38-72) a
+ * failed C-ABI call prints csm_last_error() with file:line and abort()s;
+ * device-initialisation failure is reported from Create() as a null pointer,
+ * like LoadBitstream's bool (src/slam_launcher.cpp:83-107).
+ */
+#ifndef CSM_ADAPTERS_HPP
+#define CSM_ADAPTERS_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "csm_hip.h"
+
+namespace CsmHip {
+
+#define CSM_ASSERT_OK(ctx, expr)                                                   \
+    do {                                                                           \
+        const int rc_ = (expr);                                                    \
+        if (rc_ != 0) {                                                            \
+            std::fprintf(stderr, "Assertion failed: %s == 0 (rc %d: %s) at %s:%d\n", \
+                         #expr, rc_, csm_last_error(ctx), __FILE__, __LINE__);     \
+            std::abort();                                                          \
+        }                                                                          \
+    } while (0)
+
+/* inc/pose.hpp:17-46 */
+template <typename T>
+struct RobotPose2D {
+    T mX, mY, mTheta;
+};
+
+/* What a matcher reads of GridMap (inc/grid_map_new/grid_map.hpp): the dense
+ * export of CopyValues (src/grid_map_new/grid_map.cpp:439-457) plus geometry
+ * (inc/grid_map_new/grid_map_geometry.hpp:228-240). mId plays LocalMapId::mId;
+ * kInvalidId marks a throw-away map (the frontend's latest map), as
+ * LocalMapId::Invalid does in scan_matcher_correlative_fpga.cpp:177-184. */
+struct GridMapView {
+    static constexpr std::uint64_t kInvalidId = ~0ull;
+    const std::uint16_t* mValues = nullptr;   /* row-major rows*cols */
+    int mRows = 0, mCols = 0;
+    double mResolution = 0.0;
+    double mPosOffsetX = 0.0, mPosOffsetY = 0.0;
+    std::uint64_t mId = kInvalidId;
+};
+
+/* What a matcher reads of Sensor::ScanData<double>
+ * (inc/sensor/sensor_data.hpp:63-185) */
+struct ScanDataView {
+    const double* mAngles = nullptr;
+    const double* mRanges = nullptr;
+    std::size_t mNumOfScans = 0;
+    RobotPose2D<double> mRelativeSensorPose { 0.0, 0.0, 0.0 };
+};
+
+/* inc/mapping/scan_matcher.hpp:27-50 */
+struct ScanMatchingQuery {
+    GridMapView mGridMap;
+    ScanDataView mScanData;
+    RobotPose2D<double> mMapLocalInitialPose;
+};
+
+/* inc/mapping/scan_matcher.hpp:53-82. Cost and covariance come from the
+ * caller's CostFunction (scan_matcher_correlative.cpp:209-219): pass a
+ * callback, or leave them zero. */
+struct ScanMatchingSummary {
+    bool mPoseFound = false;
+    double mNormalizedCost = 0.0;
+    RobotPose2D<double> mMapLocalInitialPose { 0, 0, 0 };
+    RobotPose2D<double> mEstimatedPose { 0, 0, 0 };
+    double mEstimatedCovariance[9] = { 0 };
+    /* extras the reference observes as metrics
+     * (scan_matcher_correlative.cpp:222-236) */
+    RobotPose2D<double> mBestSensorPose { 0, 0, 0 };
+    double mScoreValue = 0.0;
+    int mWinSizeX = 0, mWinSizeY = 0, mWinSizeTheta = 0;
+    double mStepSizeX = 0, mStepSizeY = 0, mStepSizeTheta = 0;
+    double mInputSetupTime = 0, mOptimizationTime = 0;   /* micro seconds */
+    long long mNumOfCandidates = 0;
+    std::uint32_t mFlags = 0;
+};
+
+/* Cost / covariance hook: void(query, bestSensorPose, &normalizedCost, cov[9]) */
+using CostCallback = void (*)(const ScanMatchingQuery&, const RobotPose2D<double>&, double*,
+                              double*);
+
+namespace detail {
+struct CtxDeleter {
+    void operator()(csm_ctx* c) const { if (c) csm_destroy(c); }
+};
+using CtxPtr = std::unique_ptr<csm_ctx, CtxDeleter>;
+
+inline CtxPtr MakeContext(int deviceId)
+{
+    csm_config cfg {};
+    cfg.device_id = deviceId;
+    csm_ctx* raw = nullptr;
+    if (csm_create(&cfg, &raw) != 0)
+        return CtxPtr();
+    return CtxPtr(raw);
+}
+
+inline csm_scan ToScan(const ScanDataView& s)
+{
+    csm_scan out {};
+    out.angles = s.mAngles;
+    out.ranges = s.mRanges;
+    out.n_points = static_cast<std::int32_t>(s.mNumOfScans);
+    out.relative_sensor_pose[0] = s.mRelativeSensorPose.mX;
+    out.relative_sensor_pose[1] = s.mRelativeSensorPose.mY;
+    out.relative_sensor_pose[2] = s.mRelativeSensorPose.mTheta;
+    return out;
+}
+
+inline void FillSummary(const csm_summary& s, const RobotPose2D<double>& initial,
+                        ScanMatchingSummary* out)
+{
+    out->mPoseFound = s.pose_found != 0;
+    out->mMapLocalInitialPose = initial;
+    out->mEstimatedPose = { s.estimated_pose[0], s.estimated_pose[1], s.estimated_pose[2] };
+    out->mBestSensorPose = { s.best_sensor_pose[0], s.best_sensor_pose[1], s.best_sensor_pose[2] };
+    out->mScoreValue = s.raw.score;
+    out->mWinSizeX = s.win_x;
+    out->mWinSizeY = s.win_y;
+    out->mWinSizeTheta = s.win_theta;
+    out->mStepSizeX = s.step_x;
+    out->mStepSizeY = s.step_y;
+    out->mStepSizeTheta = s.step_theta;
+    out->mInputSetupTime = s.input_setup_us;
+    out->mOptimizationTime = s.optimization_us;
+    out->mNumOfCandidates = s.candidates;
+    out->mFlags = s.raw.flags;
+}
+} /* namespace detail */
+
+class ScanMatcherCorrelativeHIP final {
+public:
+    /* Constructor arguments as ScanMatcherCorrelative
+     * (inc/mapping/scan_matcher_correlative.hpp:58-66); Create() returns null
+     * when no usable GPU exists. */
+    static std::unique_ptr<ScanMatcherCorrelativeHIP> Create(
+        const std::string& scanMatcherName, int lowResolution, double rangeX, double rangeY,
+        double rangeTheta, CostCallback costFunc = nullptr, int deviceId = 0)
+    {
+        detail::CtxPtr ctx = detail::MakeContext(deviceId);
+        if (!ctx)
+            return nullptr;
+        return std::unique_ptr<ScanMatcherCorrelativeHIP>(new ScanMatcherCorrelativeHIP(
+            scanMatcherName, lowResolution, rangeX, rangeY, rangeTheta, costFunc, std::move(ctx)));
+    }
+
+    ScanMatcherCorrelativeHIP(const ScanMatcherCorrelativeHIP&) = delete;
+    ScanMatcherCorrelativeHIP& operator=(const ScanMatcherCorrelativeHIP&) = delete;
+
+    const std::string& Name() const { return this->mName; }
+
+    /* ScanMatcher::OptimizePose (scan_matcher_correlative.cpp:92-115): the whole
+     * window, thresholds 0.0 / 0.0 */
+    ScanMatchingSummary OptimizePose(const ScanMatchingQuery& queryInfo)
+    {
+        return this->OptimizePose(queryInfo, 0.0, 0.0);
+    }
+
+    /* The 6-argument overload the loop detectors call
+     * (scan_matcher_correlative.cpp:118-244); the coarse map is built and cached
+     * on the device instead of being passed in. */
+    ScanMatchingSummary OptimizePose(const ScanMatchingQuery& q,
+                                     const double normalizedScoreThreshold,
+                                     const double knownRateThreshold)
+    {
+        csm_ctx* ctx = this->mCtx.get();
+        const GridMapView& g = q.mGridMap;
+        const bool temporary = g.mId == GridMapView::kInvalidId;
+        const std::uint64_t id = temporary ? (1ull << 62) : g.mId;
+        if (temporary || !csm_has_grid(ctx, id))
+            CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, id, g.mValues, g.mRows, g.mCols));
+        csm_geometry geom { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
+        const csm_scan scan = detail::ToScan(q.mScanData);
+        csm_correlative_params prm {};
+        prm.range_x = this->mRangeX;
+        prm.range_y = this->mRangeY;
+        prm.range_theta = this->mRangeTheta;
+        prm.low_resolution = this->mLowResolution;
+        prm.score_threshold = normalizedScoreThreshold;
+        prm.known_rate_threshold = knownRateThreshold;
+        const double init[3] = { q.mMapLocalInitialPose.mX, q.mMapLocalInitialPose.mY,
+                                 q.mMapLocalInitialPose.mTheta };
+        csm_summary s {};
+        CSM_ASSERT_OK(ctx, csm_correlative_match(ctx, id, &geom, &scan, init, &prm, &s));
+        if (temporary)
+            CSM_ASSERT_OK(ctx, csm_release_grid(ctx, id));
+        ScanMatchingSummary out;
+        detail::FillSummary(s, q.mMapLocalInitialPose, &out);
+        if (this->mCostFunc)
+            this->mCostFunc(q, out.mBestSensorPose, &out.mNormalizedCost, out.mEstimatedCovariance);
+        return out;
+    }
+
+private:
+    ScanMatcherCorrelativeHIP(const std::string& name, int lowResolution, double rangeX,
+                              double rangeY, double rangeTheta, CostCallback costFunc,
+                              detail::CtxPtr ctx) :
+        mName(name), mLowResolution(lowResolution), mRangeX(rangeX), mRangeY(rangeY),
+        mRangeTheta(rangeTheta), mCostFunc(costFunc), mCtx(std::move(ctx)) { }
+
+    const std::string mName;
+    const int mLowResolution;
+    const double mRangeX, mRangeY, mRangeTheta;
+    const CostCallback mCostFunc;
+    detail::CtxPtr mCtx;
+};
+
+/* inc/mapping/loop_detector.hpp:27-55, flattened to what the search reads:
+ * the reference local map (finished, immutable, keyed by LocalMapId) and the
+ * query scan node's scan + its pose local to that map
+ * (InverseCompound(localMapNode.mGlobalPose, scanNode.mGlobalPose),
+ * loop_detector_branch_bound.cpp:97-98 -- the caller passes both global poses). */
+struct LoopDetectionQuery {
+    GridMapView mReferenceLocalMap;
+    ScanDataView mQueryScanData;
+    RobotPose2D<double> mQueryScanNodeGlobalPose;
+    RobotPose2D<double> mReferenceLocalMapNodeGlobalPose;
+    int mQueryScanNodeId = 0;
+};
+using LoopDetectionQueryVector = std::vector<LoopDetectionQuery>;
+
+/* inc/mapping/loop_detector.hpp:58-92 before the final sub-pixel matcher */
+struct LoopDetectionResult {
+    RobotPose2D<double> mRelativePose;   /* estimated pose, map-local */
+    RobotPose2D<double> mLocalMapPose;
+    std::uint64_t mLocalMapNodeId;
+    int mScanNodeId;
+    double mScoreValue;
+    std::uint32_t mFlags;
+};
+using LoopDetectionResultVector = std::vector<LoopDetectionResult>;
+
+class LoopDetectorBranchBoundHIP final {
+public:
+    /* scoreThreshold / knownRateThreshold as LoopDetectorBranchBound
+     * (src/mapping/loop_detector_branch_bound.cpp:38-56); nodeHeightMax and the
+     * search ranges as its ScanMatcherBranchBound
+     * (src/scan_matcher_factory.cpp:22-26). */
+    static std::unique_ptr<LoopDetectorBranchBoundHIP> Create(
+        const std::string& loopDetectorName, int nodeHeightMax, double rangeX, double rangeY,
+        double rangeTheta, double scoreThreshold, double knownRateThreshold, int deviceId = 0)
+    {
+        if (!(scoreThreshold > 0.0 && scoreThreshold <= 1.0) ||
+            !(knownRateThreshold > 0.0 && knownRateThreshold <= 1.0))
+            return nullptr;
+        detail::CtxPtr ctx = detail::MakeContext(deviceId);
+        if (!ctx)
+            return nullptr;
+        return std::unique_ptr<LoopDetectorBranchBoundHIP>(new LoopDetectorBranchBoundHIP(
+            loopDetectorName, nodeHeightMax, rangeX, rangeY, rangeTheta, scoreThreshold,
+            knownRateThreshold, std::move(ctx)));
+    }
+
+    const std::string& Name() const { return this->mName; }
+
+    /* LoopDetector::Detect: results only for the queries where a pose was
+     * found, in query order (loop_detector_branch_bound.cpp:107-135). */
+    LoopDetectionResultVector Detect(const LoopDetectionQueryVector& queries)
+    {
+        LoopDetectionResultVector results;
+        if (queries.empty())
+            return results;
+        csm_ctx* ctx = this->mCtx.get();
+        std::vector<csm_loop_query> flat(queries.size());
+        for (std::size_t i = 0; i < queries.size(); ++i) {
+            const LoopDetectionQuery& q = queries[i];
+            const GridMapView& g = q.mReferenceLocalMap;
+            /* finished local maps are immutable: upload once per id
+             * (mPrecompMaps, loop_detector_branch_bound.hpp:98) */
+            if (!csm_has_grid(ctx, g.mId))
+                CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, g.mId, g.mValues, g.mRows, g.mCols));
+            csm_loop_query& f = flat[i];
+            f.map_id = g.mId;
+            f.geometry = { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
+            f.scan = detail::ToScan(q.mQueryScanData);
+            const double start[3] = { q.mReferenceLocalMapNodeGlobalPose.mX,
+                                      q.mReferenceLocalMapNodeGlobalPose.mY,
+                                      q.mReferenceLocalMapNodeGlobalPose.mTheta };
+            const double end[3] = { q.mQueryScanNodeGlobalPose.mX, q.mQueryScanNodeGlobalPose.mY,
+                                    q.mQueryScanNodeGlobalPose.mTheta };
+            csm_host_inverse_compound(start, end, f.initial_pose);
+        }
+        csm_bnb_params prm {};
+        prm.range_x = this->mRangeX;
+        prm.range_y = this->mRangeY;
+        prm.range_theta = this->mRangeTheta;
+        prm.node_height_max = this->mNodeHeightMax;
+        prm.score_threshold = this->mScoreThreshold;
+        prm.known_rate_threshold = this->mKnownRateThreshold;
+        std::vector<csm_summary> out(queries.size());
+        CSM_ASSERT_OK(ctx, csm_bnb_match_batch(ctx, flat.data(), static_cast<std::int32_t>(flat.size()),
+                                               &prm, out.data()));
+        for (std::size_t i = 0; i < queries.size(); ++i) {
+            if (!out[i].pose_found)
+                continue;
+            results.push_back(LoopDetectionResult {
+                { out[i].estimated_pose[0], out[i].estimated_pose[1], out[i].estimated_pose[2] },
+                queries[i].mReferenceLocalMapNodeGlobalPose, queries[i].mReferenceLocalMap.mId,
+                queries[i].mQueryScanNodeId, out[i].raw.score, out[i].raw.flags });
+        }
+        return results;
+    }
+
+private:
+    LoopDetectorBranchBoundHIP(const std::string& name, int nodeHeightMax, double rangeX,
+                               double rangeY, double rangeTheta, double scoreThreshold,
+                               double knownRateThreshold, detail::CtxPtr ctx) :
+        mName(name), mNodeHeightMax(nodeHeightMax), mRangeX(rangeX), mRangeY(rangeY),
+        mRangeTheta(rangeTheta), mScoreThreshold(scoreThreshold),
+        mKnownRateThreshold(knownRateThreshold), mCtx(std::move(ctx)) { }
+
+    const std::string mName;
+    const int mNodeHeightMax;
+    const double mRangeX, mRangeY, mRangeTheta;
+    const double mScoreThreshold, mKnownRateThreshold;
+    detail::CtxPtr mCtx;
+};
+
+} /* namespace CsmHip */
+#endif /* CSM_ADAPTERS_HPP */
