@@ -66,7 +66,7 @@ struct csm_ctx {
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
-    DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k;
+    DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc;
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     int last_lstride = 0, last_R = 0, last_cbx = 0, last_groups = 0, last_ncb = 0;
@@ -554,6 +554,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
 
 
 const uint32_t kTieCap = 1u << 16;
+const uint32_t kUncCap = 4096;
 
 /* Several candidates share the best integer key: collect them with a second
  * fine pass, replay each in f64, pick like the reference's strict `<`. */
@@ -745,7 +746,8 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
-                       &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k };
+                       &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
+                       &ctx->scan_dev, &ctx->unc };
     for (DevBuf* b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -1116,15 +1118,95 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     w.min_known = csm_host_min_known(scan->n_points, prm->known_rate_threshold);
     w.score_threshold = prm->score_threshold;
 
+    /* Projection on the device with a per-entry certificate; the host
+     * recomputes (glibc) only the entries that could not be certified. */
     const size_t hn = (size_t)w.n_theta * w.n_points;
-    std::vector<int32_t> col(hn), row(hn);
-    rc = csm_host_project(geom, out->sensor_pose, out->step_theta, out->win_theta, scan->angles,
-                          scan->ranges, scan->n_points, col.data(), row.data(), nullptr, nullptr);
-    if (rc)
-        return fail(ctx, rc, "projection failed");
-    rc = csm_score_window(ctx, map_id, &w, col.data(), row.data(), &out->raw);
-    if (rc)
-        return rc;
+    const int n = scan->n_points;
+    Plan p;
+    if ((rc = make_plan(ctx, *g, &w, &p))) return rc;
+    if ((rc = ensure(ctx, ctx->hits, hn * 8 + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->scan_dev, (size_t)n * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->unc, 16 + (size_t)kUncCap * 4))) return rc;
+    int32_t* col_dev = reinterpret_cast<int32_t*>(ctx->hits.p);
+    int32_t* row_dev = col_dev + hn;
+    csm_result* res_dev = reinterpret_cast<csm_result*>(row_dev + hn);
+    double* ang_dev = reinterpret_cast<double*>(ctx->scan_dev.p);
+    double* rng_dev = ang_dev + n;
+    uint32_t* unc_count = reinterpret_cast<uint32_t*>(ctx->unc.p);
+    uint32_t* unc_list = unc_count + 4;
+    HIP_TRY(ctx, hipMemcpyAsync(ang_dev, scan->angles, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(rng_dev, scan->ranges, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(unc_count, 0, 4, ctx->stream));
+    ProjJob pj;
+    std::memset(&pj, 0, sizeof(pj));
+    pj.angles = ang_dev;
+    pj.ranges = rng_dev;
+    pj.hit_col = col_dev;
+    pj.hit_row = row_dev;
+    pj.unc_count = unc_count;
+    pj.unc_list = unc_list;
+    pj.unc_cap = kUncCap;
+    pj.n_theta = w.n_theta;
+    pj.n_points = n;
+    pj.win_theta = out->win_theta;
+    pj.sensor_x = out->sensor_pose[0];
+    pj.sensor_y = out->sensor_pose[1];
+    pj.sensor_theta = out->sensor_pose[2];
+    pj.step_theta = out->step_theta;
+    pj.off_x = geom->offset_x;
+    pj.off_y = geom->offset_y;
+    pj.res = geom->resolution;
+    {
+        ScopedTimer tm(ctx, "project");
+        hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), w.n_theta), dim3(kBlock), 0,
+                           ctx->stream, pj);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
+    if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
+    uint32_t n_unc = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_unc, unc_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&out->raw, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_unc > 0) {
+        /* recompute the uncertified entries exactly as the reference does */
+        std::vector<int32_t> col(hn), row(hn);
+        HIP_TRY(ctx, hipMemcpy(col.data(), col_dev, hn * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(row.data(), row_dev, hn * 4, hipMemcpyDeviceToHost));
+        bool patched = false;
+        if (n_unc > kUncCap) {
+            std::vector<int32_t> c2(hn), r2(hn);
+            csm_host_project(geom, out->sensor_pose, out->step_theta, out->win_theta, scan->angles,
+                             scan->ranges, n, c2.data(), r2.data(), nullptr, nullptr);
+            patched = c2 != col || r2 != row;
+            col.swap(c2);
+            row.swap(r2);
+        } else {
+            std::vector<uint32_t> list(n_unc);
+            HIP_TRY(ctx, hipMemcpy(list.data(), unc_list, (size_t)n_unc * 4, hipMemcpyDeviceToHost));
+            for (uint32_t idx : list) {
+                const int t = (int)(idx / (uint32_t)n) - out->win_theta;
+                const int i = (int)(idx % (uint32_t)n);
+                const double theta = out->sensor_pose[2] + out->step_theta * t;
+                const double hx = out->sensor_pose[0] + scan->ranges[i] * std::cos(theta + scan->angles[i]);
+                const double hy = out->sensor_pose[1] + scan->ranges[i] * std::sin(theta + scan->angles[i]);
+                const int32_t c = static_cast<int>(std::floor((hx - geom->offset_x) / geom->resolution));
+                const int32_t r = static_cast<int>(std::floor((hy - geom->offset_y) / geom->resolution));
+                if (c != col[idx] || r != row[idx]) {
+                    col[idx] = c;
+                    row[idx] = r;
+                    patched = true;
+                }
+            }
+        }
+        if (patched) {
+            HIP_TRY(ctx, hipMemcpy(col_dev, col.data(), hn * 4, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(row_dev, row.data(), hn * 4, hipMemcpyHostToDevice));
+            if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
+            if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
+            HIP_TRY(ctx, hipMemcpy(&out->raw, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost));
+        }
+    }
     const auto t2 = std::chrono::steady_clock::now();
 
     out->pose_found = out->raw.found;
@@ -1222,11 +1304,27 @@ struct HeapNode {
  * src/mapping/scan_matcher_branch_bound.cpp:156-231) reading those scores
  * instead of calling Score(). No score is computed on the CPU. */
 int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BnbPrep& p, const csm_summary& o,
-                const csm_bnb_params* prm, const double* d_rc, const double* d_rs,
-                csm_result* res)
+                const csm_bnb_params* prm, csm_result* res)
 {
     const int H = prm->node_height_max;
     const int nx = p.nx, ny = p.ny;
+    /* the exact path needs the host's own r*cos / r*sin (glibc) */
+    const size_t hn = (size_t)p.n_theta * p.n;
+    std::vector<double> prod(2 * hn);
+    {
+        std::vector<int32_t> col(hn), row(hn);
+        int prc = csm_host_project(&q.geometry, o.sensor_pose, o.step_theta, p.win_t, q.scan.angles,
+                                   q.scan.ranges, p.n, col.data(), row.data(), prod.data(),
+                                   prod.data() + hn);
+        if (prc)
+            return fail(ctx, prc, "projection failed");
+    }
+    int rc0 = ensure(ctx, ctx->ex_coarse, 2 * hn * 8);
+    if (rc0)
+        return rc0;
+    double* d_rc = reinterpret_cast<double*>(ctx->ex_coarse.p);
+    double* d_rs = d_rc + hn;
+    HIP_TRY(ctx, hipMemcpyAsync(d_rc, prod.data(), 2 * hn * 8, hipMemcpyHostToDevice, ctx->stream));
     std::vector<std::vector<double>> sc(H + 1);
     std::vector<std::vector<uint32_t>> kn(H + 1);
     int rc;
@@ -1367,33 +1465,19 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
     const int nx = pp[0].nx, ny = pp[0].ny;
 
-    std::vector<double> prod(hit_total * 2);
-    double* h_rc = prod.data();
-    double* h_rs = prod.data() + hit_total;
-    {
-        unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        nthreads = std::min<unsigned>(nthreads, nq);
-        std::vector<std::thread> pool;
-        std::vector<int> status(nq, 0);
-        for (unsigned w = 0; w < nthreads; ++w)
-            pool.emplace_back([&, w]() {
-                std::vector<int32_t> col, row;
-                for (int k = w; k < nq; k += nthreads) {
-                    const csm_loop_query& q = queries[idx[k]];
-                    const BnbPrep& p = pp[k];
-                    col.resize((size_t)p.n_theta * p.n);
-                    row.resize((size_t)p.n_theta * p.n);
-                    status[k] = csm_host_project(&q.geometry, out[idx[k]].sensor_pose,
-                                                 out[idx[k]].step_theta, p.win_t, q.scan.angles,
-                                                 q.scan.ranges, p.n, col.data(), row.data(),
-                                                 h_rc + p.hit_off, h_rs + p.hit_off);
-                }
-            });
-        for (auto& t : pool)
-            t.join();
-        for (int k = 0; k < nq; ++k)
-            if (status[k])
-                return fail(ctx, status[k], "projection failed for query %d", idx[k]);
+    /* scans go to the device as they are (angles, ranges); the projection runs
+     * there with a per-entry certificate (k_project) */
+    std::vector<size_t> scan_off(nq);
+    size_t scan_total = 0;
+    for (int k = 0; k < nq; ++k) {
+        scan_off[k] = scan_total;
+        scan_total += 2 * (size_t)pp[k].n;
+    }
+    std::vector<double> scans(scan_total);
+    for (int k = 0; k < nq; ++k) {
+        const csm_loop_query& q = queries[idx[k]];
+        std::memcpy(scans.data() + scan_off[k], q.scan.angles, (size_t)pp[k].n * 8);
+        std::memcpy(scans.data() + scan_off[k] + pp[k].n, q.scan.ranges, (size_t)pp[k].n * 8);
     }
 
     /* ---- launch geometry shared by the group ---- */
@@ -1415,7 +1499,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         p.best_off = best_total;
         best_total += (size_t)p.n_theta * ncb;
     }
-    if ((rc = ensure(ctx, ctx->b_prod, hit_total * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->b_prod, scan_total * 8 + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_hits, hit_total * 8))) return rc;
     if ((rc = ensure(ctx, ctx->b_sorted, hit_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tile_total * sizeof(TileRec)))) return rc;
@@ -1423,12 +1507,11 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     if ((rc = ensure(ctx, ctx->b_lvl, lvl_total * 8 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->b_best, best_total * sizeof(BlockBest)))) return rc;
     if ((rc = ensure(ctx, ctx->b_out, (size_t)nq * (sizeof(csm_result) + 4)))) return rc;
-    const size_t jobs_bytes = (size_t)nq * (sizeof(IndexJob) + sizeof(BinJob) + sizeof(FinalJob) +
+    const size_t jobs_bytes = (size_t)nq * (sizeof(ProjJob) + sizeof(BinJob) + sizeof(FinalJob) +
                                             (size_t)(H + 1) * sizeof(ScoreJob));
     if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + 1024))) return rc;
 
-    double* d_rc = reinterpret_cast<double*>(ctx->b_prod.p);
-    double* d_rs = d_rc + hit_total;
+    double* d_scans = reinterpret_cast<double*>(ctx->b_prod.p);
     int32_t* d_col = reinterpret_cast<int32_t*>(ctx->b_hits.p);
     int32_t* d_row = d_col + hit_total;
     uint32_t* d_sorted = reinterpret_cast<uint32_t*>(ctx->b_sorted.p);
@@ -1440,13 +1523,13 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     csm_result* d_out = reinterpret_cast<csm_result*>(ctx->b_out.p);
     uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_out + nq);
 
-    HIP_TRY(ctx, hipMemcpyAsync(d_rc, prod.data(), hit_total * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_scans, scans.data(), scan_total * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, (size_t)nq * 4, ctx->stream));
     if (lvl_total)
         HIP_TRY(ctx, hipMemsetAsync(d_lvl_s, 0, lvl_total * 8, ctx->stream));
 
     /* ---- job tables ---- */
-    std::vector<IndexJob> ij(nq);
+    std::vector<ProjJob> ij(nq);
     std::vector<BinJob> bj(nq);
     std::vector<FinalJob> fj(nq);
     std::vector<std::vector<ScoreJob>> sj(H + 1, std::vector<ScoreJob>(nq));
@@ -1458,26 +1541,30 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         const int x_lo = -p.win_x, y_lo = -p.win_y;
         const int min_known = csm_host_min_known(p.n, prm->known_rate_threshold);
 
-        IndexJob& I = ij[k];
+        ProjJob& I = ij[k];
         std::memset(&I, 0, sizeof(I));
-        I.r_cos = d_rc + p.hit_off;
-        I.r_sin = d_rs + p.hit_off;
+        I.angles = d_scans + scan_off[k];
+        I.ranges = d_scans + scan_off[k] + p.n;
         I.hit_col = d_col + p.hit_off;
         I.hit_row = d_row + p.hit_off;
         I.flags = d_flags + k;
         I.n_theta = p.n_theta;
         I.n_points = p.n;
+        I.win_theta = p.win_t;
+        I.sensor_x = o.sensor_pose[0];
+        I.sensor_y = o.sensor_pose[1];
+        I.sensor_theta = o.sensor_pose[2];
+        I.step_theta = o.step_theta;
+        I.off_x = q.geometry.offset_x;
+        I.off_y = q.geometry.offset_y;
+        I.res = q.geometry.resolution;
+        I.check_nodes = 1;
         I.x_lo = x_lo;
         I.y_lo = y_lo;
         I.nx = nx;
         I.ny = ny;
-        I.sensor_x = o.sensor_pose[0];
-        I.sensor_y = o.sensor_pose[1];
         I.step_x = o.step_x;
         I.step_y = o.step_y;
-        I.off_x = q.geometry.offset_x;
-        I.off_y = q.geometry.offset_y;
-        I.res = q.geometry.resolution;
 
         BinJob& B = bj[k];
         std::memset(&B, 0, sizeof(B));
@@ -1586,7 +1673,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     jb = reinterpret_cast<char*>(ctx->b_jobs.p);
     char *d_ij, *d_bj, *d_fj;
     std::vector<char*> d_sj(H + 1);
-    HIP_TRY(ctx, put(ij.data(), nq * sizeof(IndexJob), &d_ij));
+    HIP_TRY(ctx, put(ij.data(), nq * sizeof(ProjJob), &d_ij));
     HIP_TRY(ctx, put(bj.data(), nq * sizeof(BinJob), &d_bj));
     HIP_TRY(ctx, put(fj.data(), nq * sizeof(FinalJob), &d_fj));
     for (int h = 0; h <= H; ++h)
@@ -1594,9 +1681,9 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
 
     /* ---- launches ---- */
     {
-        ScopedTimer tm(ctx, "bnb_index");
-        hipLaunchKernelGGL(k_bnb_index, dim3(ceil_div(n_points_max, kBlock), n_theta_max, nq),
-                           dim3(kBlock), 0, ctx->stream, reinterpret_cast<const IndexJob*>(d_ij));
+        ScopedTimer tm(ctx, "project");
+        hipLaunchKernelGGL(k_project_batch, dim3(ceil_div(n_points_max, kBlock), n_theta_max, nq),
+                           dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ProjJob*>(d_ij));
         HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -1648,8 +1735,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         const csm_loop_query& q = queries[idx[k]];
         csm_summary& o = out[idx[k]];
         if (res[k].flags & (CSM_FLAG_EDGE_BAND | CSM_FLAG_KEY_TIE | CSM_FLAG_PROJ_DELTA))
-            if ((rc = bnb_literal(ctx, q, pp[k], o, prm, d_rc + pp[k].hit_off, d_rs + pp[k].hit_off,
-                                  &res[k])))
+            if ((rc = bnb_literal(ctx, q, pp[k], o, prm, &res[k])))
                 return rc;
         o.raw = res[k];
         o.pose_found = o.raw.found;

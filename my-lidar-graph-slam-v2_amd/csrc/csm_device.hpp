@@ -135,6 +135,31 @@ struct IndexJob {
     double off_x, off_y, res;
 };
 
+/* Device-side projection with a certificate. The device evaluates
+ * ScanData::HitPoint + PositionToIndex with its own sin / cos; an entry is
+ * trusted only where the cell coordinate is farther from a cell edge than a
+ * bound on |host value - device value| (both libms are accurate to a few ulp),
+ * so the floor is provably the one glibc would give. The few entries that
+ * cannot be certified are listed for the host to recompute. */
+struct ProjJob {
+    const double* angles;      /* [n_points] */
+    const double* ranges;
+    int32_t* hit_col;          /* [n_theta][n_points] */
+    int32_t* hit_row;
+    uint32_t* unc_count;       /* [1] */
+    uint32_t* unc_list;        /* [unc_cap] flat index t * n_points + i */
+    uint32_t  unc_cap;
+    int32_t n_theta, n_points, win_theta;
+    double sensor_x, sensor_y, sensor_theta, step_theta;
+    double off_x, off_y, res;
+    /* branch and bound: also certify every per-node projection
+     * floor((sensor + x*step + r*cos - off) / res) == base + x */
+    int32_t check_nodes;
+    int32_t x_lo, y_lo, nx, ny;
+    double step_x, step_y;
+    uint32_t* flags;           /* CSM_FLAG_PROJ_DELTA when a node cannot be certified */
+};
+
 /* Exhaustive f64 scores (beam order) of one level; literal / tie paths. */
 struct ExactJob {
     const uint16_t* cells;

@@ -911,6 +911,80 @@ __device__ __forceinline__ bool index_is(double hit, double off, double res, dou
     return (int)floor(t / res) == expect;
 }
 
+/* Bound on |q_host - q_device| for q = (sensor + r*trig - off) / res, in
+ * cells: 3 ulp between the two libms on the trig value, one rounding per
+ * arithmetic step on either side; the caller multiplies by a safety factor. */
+__device__ __forceinline__ double proj_err_bound(double r, double hit, double off, double res,
+                                                 double q)
+{
+    return (fabs(r) * 8e-16 + (fabs(hit) + fabs(off)) * 4e-16) / res + fabs(q) * 4e-16;
+}
+
+__device__ __forceinline__ void proj_body(const ProjJob& job)
+{
+    const int t = blockIdx.y;
+    if (t >= job.n_theta)
+        return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= job.n_points)
+        return;
+    /* scan_matcher_correlative.cpp:163-166: theta = sensor.theta + stepTheta * t */
+    const int tt = t - job.win_theta;
+    const double theta = job.sensor_theta + job.step_theta * tt;
+    const double arg = theta + job.angles[i];
+    const double r = job.ranges[i];
+    const double rc = r * cos(arg);
+    const double rs = r * sin(arg);
+    const double hx = job.sensor_x + rc, hy = job.sensor_y + rs;
+    const double qx = (hx - job.off_x) / job.res, qy = (hy - job.off_y) / job.res;
+    const double fx = floor(qx), fy = floor(qy);
+    const double mx = 64.0 * proj_err_bound(r, hx, job.off_x, job.res, qx);
+    const double my = 64.0 * proj_err_bound(r, hy, job.off_y, job.res, qy);
+    const size_t idx = (size_t)t * job.n_points + i;
+    const int col = (int)fx, row = (int)fy;
+    job.hit_col[idx] = col;
+    job.hit_row[idx] = row;
+    bool uncertain = !(qx - fx > mx && qx - fx < 1.0 - mx && qy - fy > my && qy - fy < 1.0 - my);
+    if (job.check_nodes && !uncertain) {
+        /* appendNode's pose (scan_matcher_branch_bound.cpp:156-176) */
+        for (int xi = 0; xi < job.nx && !uncertain; ++xi) {
+            const int x = job.x_lo + xi;
+            const double h = (job.sensor_x + x * job.step_x) + rc;
+            const double q = (h - job.off_x) / job.res;
+            const double f = floor(q);
+            const double m = 64.0 * proj_err_bound(r, h, job.off_x, job.res, q);
+            uncertain = !((int)f == col + x && q - f > m && q - f < 1.0 - m);
+        }
+        for (int yi = 0; yi < job.ny && !uncertain; ++yi) {
+            const int y = job.y_lo + yi;
+            const double h = (job.sensor_y + y * job.step_y) + rs;
+            const double q = (h - job.off_y) / job.res;
+            const double f = floor(q);
+            const double m = 64.0 * proj_err_bound(r, h, job.off_y, job.res, q);
+            uncertain = !((int)f == row + y && q - f > m && q - f < 1.0 - m);
+        }
+    }
+    if (uncertain) {
+        if (job.check_nodes) {
+            atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
+        } else {
+            const uint32_t pos = atomicAdd(job.unc_count, 1u);
+            if (pos < job.unc_cap)
+                job.unc_list[pos] = (uint32_t)idx;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_project(ProjJob job)
+{
+    proj_body(job);
+}
+
+__global__ __launch_bounds__(kBlock) void k_project_batch(const ProjJob* jobs)
+{
+    proj_body(jobs[blockIdx.z]);
+}
+
 __global__ __launch_bounds__(kBlock) void k_bnb_index(const IndexJob* jobs)
 {
     const IndexJob& job = jobs[blockIdx.z];
