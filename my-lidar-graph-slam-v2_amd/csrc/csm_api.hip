@@ -66,10 +66,9 @@ struct csm_ctx {
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
-    DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc;
+    DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
-    int last_lstride = 0, last_R = 0, last_cbx = 0, last_groups = 0, last_ncb = 0;
     bool timing = false;
     std::map<std::string, KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -164,65 +163,114 @@ double value_to_probability(unsigned v)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+
+
+
+
+const int kCoarseSlices = 8;
+
+/* Launch geometry of one scoring pass (one level of one window shape). */
+struct PassPlan {
+    int nx = 0, ny = 0, stride = 1, log2s = 0;
+    int cbx = 0, groups = 0, R = 0, ncbx = 0, ncby = 0, lstride = 0;
+    int ncb() const { return ncbx * ncby; }
+};
+
+int ilog2_exact(int v)
+{
+    int l = 0;
+    while ((1 << l) < v)
+        ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+/* Pick the candidate block (cbx wide, groups * R tall) for nx x ny candidates
+ * `stride` cells apart. Fails (returns false) if nothing fits the LDS limits. */
+bool plan_pass(int nx, int ny, int stride, PassPlan* out)
+{
+    PassPlan p;
+    p.nx = nx;
+    p.ny = ny;
+    p.stride = stride;
+    p.log2s = ilog2_exact(stride);
+    const bool strided = stride > 1;
+    const int max_ls = 192;
+    /* columns: 7 (alignment) + tile + (cbx - 1) * stride + 1 <= lstride */
+    const int max_cbx = std::min(120, (max_ls - kTile - 8) / stride + 1);
+    if (max_cbx < 1)
+        return false;
+    const int nb = ceil_div(nx, max_cbx);
+    p.cbx = ceil_div(nx, nb);
+    p.ncbx = ceil_div(nx, p.cbx);
+    const int need = kTile + 8 + (p.cbx - 1) * stride;
+    const int cand_ls[] = { 96, 128, 160, 192 };
+    for (int ls : cand_ls) {
+        /* phase-major layout: column phase p owns floor(ls / stride) cells */
+        const int need8 = (need + 7) & ~7;
+        if ((ls / stride) * stride < need8 || (strided && ls != 128 && ls != 192))
+            continue;
+        p.lstride = ls;
+        break;
+    }
+    if (!p.lstride)
+        return false;
+    /* rows: stride-1 regions hold kTile + cby - 1 rows, strided ones
+     * (ceil(kTile / s) + cby - 1) * s */
+    const int max_cby = strided ? kMaxRegionRowsStrided / stride - (kTile + stride - 1) / stride + 1
+                                : kMaxRegionRows - kTile + 1;
+    if (max_cby < 1)
+        return false;
+    int g = std::max(1, kBlock / p.cbx);
+    static const int r_fine[] = { 4, 5, 6, 7, 8 };
+    static const int r_strided[] = { 1, 2, 4 };
+    const int* rs = strided ? r_strided : r_fine;
+    const int nrs = strided ? 3 : 5;
+    const char* force = getenv("CSM_FORCE_R");   /* tuning knob */
+    long best_cost = -1;
+    for (int k = 0; k < nrs; ++k) {
+        const int r = rs[k];
+        if (force && !strided && atoi(force) != r)
+            continue;
+        if (r > max_cby)
+            continue;
+        int gg = std::min(g, ceil_div(ny, r));
+        gg = std::max(1, std::min(gg, max_cby / r));
+        const int nby = ceil_div(ny, gg * r);
+        /* per (tile, block): ~108 r instruction slots of gathering (~90 beams)
+         * + staging that grows with the rows the block spans; times the
+         * number of blocks along y. Calibrated on config 2 (R 7 < 4 < 8). */
+        const long cost = (long)nby * (1080L * r + 1000L + 25L * gg * r * stride) +
+                          (long)(kBlock - gg * p.cbx);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && r > p.R)) {
+            best_cost = cost;
+            p.R = r;
+            p.groups = gg;
+            p.ncby = nby;
+        }
+    }
+    if (best_cost < 0)
+        return false;
+    *out = p;
+    return true;
+}
+
+size_t pass_lds_bytes(const PassPlan& p)
+{
+    const int cby = p.groups * p.R;
+    const int rows = p.stride > 1 ? ((kTile + p.stride - 1) / p.stride + cby - 1) * p.stride
+                                  : kTile + cby - 1;
+    return (size_t)rows * p.lstride * 4 + kPbMax * 4;
+}
+
 /* Launch geometry of one search window. */
 struct Plan {
     int n_theta = 0, n = 0;
     int win_x = 0, win_y = 0, L = 1;
     int nxc = 0, nyc = 0, nx = 0, ny = 0;
     int x_lo = 0, y_lo = 0, x_hi = 0, y_hi = 0;
-    int lstride = 64;
-    int cbx = 0, groups = 0, R = 8, ncbx = 0, ncby = 0;
-    int c_cbx = 0, c_groups = 0, c_ncbx = 0, c_ncby = 0;
+    PassPlan fine, coarse;
     int tiles_x = 0, tiles_y = 0, max_tiles = 0;
 };
-
-const int kRChoices[] = { 4, 5, 6, 7, 8 };
-
-int pick_lstride(int need)
-{
-    return need <= 96 ? 96 : need <= 128 ? 128 : need <= 160 ? 160 : need <= 192 ? 192 : 0;
-}
-const int kCoarseSlices = 8;
-
-void plan_blocks(int nx, int ny, int stride_unused, int* cbx, int* groups, int* R,
-                 int* ncbx, int* ncby, bool fixed_r1)
-{
-    (void)stride_unused;
-    const int nb = ceil_div(nx, 120);
-    *cbx = ceil_div(nx, nb);
-    *ncbx = ceil_div(nx, *cbx);
-    int g = kBlock / *cbx;
-    if (g < 1)
-        g = 1;
-    /* the staged region may not exceed kMaxRegionRows rows */
-    const int max_cby = kMaxRegionRows - kTile + 1;
-    if (fixed_r1) {
-        *R = 1;
-        if (g > ny)
-            g = ny;
-        *groups = g;
-        *ncby = ceil_div(ny, g);
-        return;
-    }
-    /* pick R (and trim groups) minimising padded candidate rows */
-    long best_cost = -1;
-    const char* force = getenv("CSM_FORCE_R");   /* tuning knob */
-    for (int r : kRChoices) {
-        if (force && atoi(force) != r)
-            continue;
-        int gg = std::min(g, ceil_div(ny, r));
-        gg = std::max(1, std::min(gg, max_cby / r));
-        const int nby = ceil_div(ny, gg * r);
-        /* cost ~ lane-rows issued (idle lanes still occupy the SIMD) */
-        const long cost = (long)nby * r * 1000 / 1 + (long)(kBlock - gg * *cbx);
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && r > *R)) {
-            best_cost = cost;
-            *R = r;
-            *groups = gg;
-            *ncby = nby;
-        }
-    }
-}
 
 int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
 {
@@ -242,20 +290,10 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     p->y_lo = -w->win_y;
     p->x_hi = p->x_lo + p->nx - 1;
     p->y_hi = p->y_lo + p->ny - 1;
-    plan_blocks(p->nx, p->ny, 1, &p->cbx, &p->groups, &p->R, &p->ncbx, &p->ncby, false);
-    const int need = kTile + 7 + p->cbx;
-    p->lstride = pick_lstride(need);
-    if (!p->lstride)
-        return fail(ctx, CSM_EINVAL, "internal: candidate block too wide");
-    /* coarse pass: candidates L cells apart, must fit the same LDS pitch */
-    p->c_cbx = std::min(p->nxc, (p->lstride - kTile - 8) / p->L + 1);
-    p->c_ncbx = ceil_div(p->nxc, p->c_cbx);
-    p->c_cbx = ceil_div(p->nxc, p->c_ncbx);
-    int cg = std::max(1, kBlock / p->c_cbx);
-    cg = std::min(cg, (kMaxRegionRows - kTile) / p->L + 1);
-    cg = std::min(cg, p->nyc);
-    p->c_groups = cg;
-    p->c_ncby = ceil_div(p->nyc, cg);
+    if (!plan_pass(p->nx, p->ny, 1, &p->fine))
+        return fail(ctx, CSM_EINVAL, "internal: no launch geometry for the fine level");
+    if (p->L > 1 && !plan_pass(p->nxc, p->nyc, p->L, &p->coarse))
+        return fail(ctx, CSM_EINVAL, "LowResolution %d too large for the coarse kernel", p->L);
     p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
     p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi, kTile);
     p->max_tiles = std::min(p->n, p->tiles_x * p->tiles_y) + p->n / kPbMax + 1;
@@ -275,50 +313,78 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
     return CSM_OK;
 }
 
-#define LAUNCH_SCORE(LS, RR, ST)                                                      \
-    do {                                                                              \
-        int rc_ = set_lds(ctx, k_score<LS, RR, ST>, lds);                             \
-        if (rc_)                                                                      \
-            return rc_;                                                               \
-        hipLaunchKernelGGL((k_score<LS, RR, ST>), grid, dim3(kBlock), lds,            \
-                           ctx->stream, job, cbx, groups);                            \
+/* Template dispatch: stride-1 kernels for LSTRIDE in {96,128,160,192} x R in
+ * {4..8}; strided kernels for LSTRIDE in {128,192} x R in {1,2,4}. */
+#define SCORE_CASE(LS, RR, ST, CALL)                                                   \
+    if (pp.lstride == LS && pp.R == RR && mode == ST) {                                \
+        CALL(LS, RR, ST);                                                              \
+        launched = true;                                                               \
+    }
+#define SCORE_DISPATCH(CALL)                                                           \
+    do {                                                                               \
+        SCORE_CASE(96, 4, 0, CALL) SCORE_CASE(96, 5, 0, CALL)                          \
+        SCORE_CASE(96, 6, 0, CALL) SCORE_CASE(96, 7, 0, CALL)                          \
+        SCORE_CASE(96, 8, 0, CALL) SCORE_CASE(128, 4, 0, CALL)                         \
+        SCORE_CASE(128, 5, 0, CALL) SCORE_CASE(128, 6, 0, CALL)                        \
+        SCORE_CASE(128, 7, 0, CALL) SCORE_CASE(128, 8, 0, CALL)                        \
+        SCORE_CASE(160, 4, 0, CALL) SCORE_CASE(160, 5, 0, CALL)                        \
+        SCORE_CASE(160, 6, 0, CALL) SCORE_CASE(160, 7, 0, CALL)                        \
+        SCORE_CASE(160, 8, 0, CALL) SCORE_CASE(192, 4, 0, CALL)                        \
+        SCORE_CASE(192, 5, 0, CALL) SCORE_CASE(192, 6, 0, CALL)                        \
+        SCORE_CASE(192, 7, 0, CALL) SCORE_CASE(192, 8, 0, CALL)                        \
+        SCORE_CASE(128, 1, 1, CALL) SCORE_CASE(128, 2, 1, CALL)                        \
+        SCORE_CASE(128, 4, 1, CALL) SCORE_CASE(192, 1, 1, CALL)                        \
+        SCORE_CASE(192, 2, 1, CALL) SCORE_CASE(192, 4, 1, CALL)                        \
+        SCORE_CASE(128, 1, 2, CALL) SCORE_CASE(128, 2, 2, CALL)                        \
+        SCORE_CASE(128, 4, 2, CALL) SCORE_CASE(192, 1, 2, CALL)                        \
+        SCORE_CASE(192, 2, 2, CALL) SCORE_CASE(192, 4, 2, CALL)                        \
     } while (0)
 
-#define DISPATCH_R(LS)                                                                \
-    switch (R) {                                                                      \
-    case 4: LAUNCH_SCORE(LS, 4, false); break;                                        \
-    case 5: LAUNCH_SCORE(LS, 5, false); break;                                        \
-    case 6: LAUNCH_SCORE(LS, 6, false); break;                                        \
-    case 7: LAUNCH_SCORE(LS, 7, false); break;                                        \
-    case 8: LAUNCH_SCORE(LS, 8, false); break;                                        \
-    default: return fail(ctx, CSM_EINVAL, "internal: R");                             \
-    }
+#define CALL_SINGLE(LS, RR, ST)                                                        \
+    do {                                                                               \
+        int rc_ = set_lds(ctx, k_score<LS, RR, ST>, lds);                              \
+        if (rc_)                                                                       \
+            return rc_;                                                                \
+        hipLaunchKernelGGL((k_score<LS, RR, ST>), grid, dim3(kBlock), lds, ctx->stream, \
+                           job, pp.cbx, pp.groups);                                    \
+    } while (0)
 
-int launch_score(csm_ctx* ctx, const ScoreJob& job, int lstride, int R, bool strided,
-                 int cbx, int groups, int ncb, int n_theta, int n_slices)
+#define CALL_BATCH(LS, RR, ST)                                                         \
+    do {                                                                               \
+        int rc_ = set_lds(ctx, k_score_batch<LS, RR, ST>, lds);                        \
+        if (rc_)                                                                       \
+            return rc_;                                                                \
+        hipLaunchKernelGGL((k_score_batch<LS, RR, ST>), grid, dim3(kBlock), lds,       \
+                           ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices);        \
+    } while (0)
+
+int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta, int n_slices)
 {
-    const dim3 grid(ncb, n_theta, n_slices);
-    const int stride = strided ? job.stride : 1;
-    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 4 + kPbMax * 4;
+    const dim3 grid(pp.ncb(), n_theta, n_slices);
+    const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
+    const size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
-    if (strided) {
-        switch (lstride) {
-        case 96: LAUNCH_SCORE(96, 1, true); break;
-        case 128: LAUNCH_SCORE(128, 1, true); break;
-        case 160: LAUNCH_SCORE(160, 1, true); break;
-        case 192: LAUNCH_SCORE(192, 1, true); break;
-        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
-        }
-    } else {
-        switch (lstride) {
-        case 96: DISPATCH_R(96); break;
-        case 128: DISPATCH_R(128); break;
-        case 160: DISPATCH_R(160); break;
-        case 192: DISPATCH_R(192); break;
-        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
-        }
-    }
+    bool launched = false;
+    SCORE_DISPATCH(CALL_SINGLE);
+    if (!launched)
+        return fail(ctx, CSM_EINVAL, "internal: no kernel for lstride %d R %d", pp.lstride, pp.R);
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
+int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const PassPlan& pp,
+                       int n_theta_max, int n_slices)
+{
+    const dim3 grid(pp.ncb(), n_theta_max, n_jobs * n_slices);
+    const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
+    const size_t lds = pass_lds_bytes(pp);
+    if (lds > 160 * 1024 - 256)
+        return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
+    bool launched = false;
+    SCORE_DISPATCH(CALL_BATCH);
+    if (!launched)
+        return fail(ctx, CSM_EINVAL, "internal: no kernel for lstride %d R %d", pp.lstride, pp.R);
     HIP_TRY(ctx, hipGetLastError());
     return CSM_OK;
 }
@@ -407,8 +473,9 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     if ((rc = ensure(ctx, ctx->misc, 256))) return rc;
     if ((rc = ensure(ctx, ctx->coarse_s, nt * p.nxc * p.nyc * 4))) return rc;
     if ((rc = ensure(ctx, ctx->coarse_k, nt * p.nxc * p.nyc * 4))) return rc;
-    const int ncb = p.ncbx * p.ncby;
+    const int ncb = p.fine.ncb();
     if ((rc = ensure(ctx, ctx->best, nt * ncb * sizeof(BlockBest)))) return rc;
+    if ((rc = ensure(ctx, ctx->sorted_rc, nt * p.n * 4))) return rc;
 
     uint32_t* flags = reinterpret_cast<uint32_t*>(ctx->misc.p);
     HIP_TRY(ctx, hipMemsetAsync(flags, 0, 4, ctx->stream));
@@ -432,7 +499,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.y_hi = p.y_hi;
     bj.tiles_x = p.tiles_x;
     bj.tiles_y = p.tiles_y;
-    bj.lstride = p.lstride;
+    bj.lstride = p.fine.lstride;
+    bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
     if (p.L > 1) {
         bj.n_band = 1;
         bj.band_win[0] = p.L;
@@ -469,6 +537,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         cj.nx = p.nxc;
         cj.ny = p.nyc;
         cj.stride = p.L;
+        cj.log2_stride = p.coarse.log2s;
+        cj.sorted_pb = bj.sorted_rc;
         cj.acc_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
         cj.acc_k = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
         cj.rank_l = 1;
@@ -479,8 +549,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         HIP_TRY(ctx, hipMemsetAsync(cj.acc_k, 0, nodes * 4, ctx->stream));
         /* few candidates per slice: split the tile list over blockIdx.z so
          * enough workgroups are in flight to hide the staging latency */
-        if ((rc = launch_score(ctx, cj, p.lstride, 1, true, p.c_cbx, p.c_groups,
-                               p.c_ncbx * p.c_ncby, p.n_theta, kCoarseSlices)))
+        if ((rc = launch_score(ctx, cj, p.coarse, p.n_theta, kCoarseSlices)))
             return rc;
     }
 
@@ -508,15 +577,10 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     }
     {
         ScopedTimer tm(ctx, "score_fine");
-        if ((rc = launch_score(ctx, fj, p.lstride, p.R, false, p.cbx, p.groups, ncb, p.n_theta, 1)))
+        if ((rc = launch_score(ctx, fj, p.fine, p.n_theta, 1)))
             return rc;
     }
     ctx->last_fine = fj;
-    ctx->last_lstride = p.lstride;
-    ctx->last_R = p.R;
-    ctx->last_cbx = p.cbx;
-    ctx->last_groups = p.groups;
-    ctx->last_ncb = ncb;
 
     FinalJob fin;
     std::memset(&fin, 0, sizeof(fin));
@@ -576,8 +640,7 @@ int resolve_ties(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p
     cj.tie_list = list;
     cj.tie_count = count;
     cj.tie_cap = kTieCap;
-    if ((rc = launch_score(ctx, cj, ctx->last_lstride, ctx->last_R, false, ctx->last_cbx,
-                           ctx->last_groups, ctx->last_ncb, p.n_theta, 1)))
+    if ((rc = launch_score(ctx, cj, p.fine, p.n_theta, 1)))
         return rc;
     TieJob tj;
     std::memset(&tj, 0, sizeof(tj));
@@ -747,7 +810,7 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
                        &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
-                       &ctx->scan_dev, &ctx->unc };
+                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc };
     for (DevBuf* b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -1229,54 +1292,6 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
 
 namespace {
 
-#define LAUNCH_SCORE_B(LS, RR, ST)                                                    \
-    do {                                                                              \
-        int rc_ = set_lds(ctx, k_score_batch<LS, RR, ST>, lds);                       \
-        if (rc_)                                                                      \
-            return rc_;                                                               \
-        hipLaunchKernelGGL((k_score_batch<LS, RR, ST>), grid, dim3(kBlock), lds,      \
-                           ctx->stream, jobs_dev, cbx, groups, n_slices);             \
-    } while (0)
-
-#define DISPATCH_R_B(LS)                                                              \
-    switch (R) {                                                                      \
-    case 4: LAUNCH_SCORE_B(LS, 4, false); break;                                      \
-    case 5: LAUNCH_SCORE_B(LS, 5, false); break;                                      \
-    case 6: LAUNCH_SCORE_B(LS, 6, false); break;                                      \
-    case 7: LAUNCH_SCORE_B(LS, 7, false); break;                                      \
-    case 8: LAUNCH_SCORE_B(LS, 8, false); break;                                      \
-    default: return fail(ctx, CSM_EINVAL, "internal: R");                             \
-    }
-
-int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, int lstride, int R,
-                       bool strided, int stride, int cbx, int groups, int ncb, int n_theta_max,
-                       int n_slices)
-{
-    const dim3 grid(ncb, n_theta_max, n_jobs * n_slices);
-    const size_t lds = (size_t)(kTile + (groups * R - 1) * stride) * lstride * 4 + kPbMax * 4;
-    if (lds > 160 * 1024 - 256)
-        return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
-    if (strided) {
-        switch (lstride) {
-        case 96: LAUNCH_SCORE_B(96, 1, true); break;
-        case 128: LAUNCH_SCORE_B(128, 1, true); break;
-        case 160: LAUNCH_SCORE_B(160, 1, true); break;
-        case 192: LAUNCH_SCORE_B(192, 1, true); break;
-        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
-        }
-    } else {
-        switch (lstride) {
-        case 96: DISPATCH_R_B(96); break;
-        case 128: DISPATCH_R_B(128); break;
-        case 160: DISPATCH_R_B(160); break;
-        case 192: DISPATCH_R_B(192); break;
-        default: return fail(ctx, CSM_EINVAL, "internal: lstride");
-        }
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
-}
-
 struct BnbPrep {
     DeviceGrid* grid = nullptr;
     int level[kMaxElig] = { 0 };   /* index into grid->levels of box-max(2^h) */
@@ -1481,12 +1496,12 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     }
 
     /* ---- launch geometry shared by the group ---- */
-    int cbx, groups, R, ncbx, ncby;
-    plan_blocks(nx, ny, 1, &cbx, &groups, &R, &ncbx, &ncby, false);
-    const int lstride = pick_lstride(kTile + 7 + cbx);
-    if (!lstride)
-        return fail(ctx, CSM_EINVAL, "internal: candidate block too wide");
-    const int ncb = ncbx * ncby;
+    std::vector<PassPlan> lp(H + 1);
+    for (int h = 0; h <= H; ++h)
+        if (!plan_pass(nx >> h, ny >> h, 1 << h, &lp[h]))
+            return fail(ctx, CSM_EINVAL, "internal: no launch geometry for level %d", h);
+    const int lstride = lp[0].lstride;
+    const int ncb = lp[0].ncb();
 
     /* ---- workspaces ---- */
     size_t lvl_total = 0, best_total = 0;
@@ -1502,6 +1517,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     if ((rc = ensure(ctx, ctx->b_prod, scan_total * 8 + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_hits, hit_total * 8))) return rc;
     if ((rc = ensure(ctx, ctx->b_sorted, hit_total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->b_sorted_rc, hit_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tile_total * sizeof(TileRec)))) return rc;
     if ((rc = ensure(ctx, ctx->b_ntiles, theta_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_lvl, lvl_total * 8 + 16))) return rc;
@@ -1515,6 +1531,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     int32_t* d_col = reinterpret_cast<int32_t*>(ctx->b_hits.p);
     int32_t* d_row = d_col + hit_total;
     uint32_t* d_sorted = reinterpret_cast<uint32_t*>(ctx->b_sorted.p);
+    uint32_t* d_sorted_rc = reinterpret_cast<uint32_t*>(ctx->b_sorted_rc.p);
     TileRec* d_tiles = reinterpret_cast<TileRec*>(ctx->b_tiles.p);
     int32_t* d_ntiles = reinterpret_cast<int32_t*>(ctx->b_ntiles.p);
     uint32_t* d_lvl_s = reinterpret_cast<uint32_t*>(ctx->b_lvl.p);
@@ -1571,6 +1588,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         B.hit_col = I.hit_col;
         B.hit_row = I.hit_row;
         B.sorted_pb = d_sorted + p.hit_off;
+        B.sorted_rc = H > 0 ? d_sorted_rc + p.hit_off : nullptr;
         B.tiles = d_tiles + p.tile_off;
         B.n_tiles = d_ntiles + p.theta_off;
         B.flags = d_flags + k;
@@ -1616,6 +1634,8 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
             S.nx = nx >> h;
             S.ny = ny >> h;
             S.stride = 1 << h;
+            S.log2_stride = h;
+            S.sorted_pb = B.sorted_rc;
             S.acc_s = d_lvl_s + p.lvl_off[h];
             S.acc_k = d_lvl_k + p.lvl_off[h];
         }
@@ -1694,28 +1714,20 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         HIP_TRY(ctx, hipGetLastError());
     }
     for (int h = H; h >= 1; --h) {
-        const int st = 1 << h;
-        const int nxh = nx >> h, nyh = ny >> h;
-        int c_cbx = std::min(nxh, (lstride - kTile - 8) / st + 1);
-        const int c_ncbx = ceil_div(nxh, c_cbx);
-        c_cbx = ceil_div(nxh, c_ncbx);
-        int cg = std::max(1, kBlock / c_cbx);
-        cg = std::min(cg, (kMaxRegionRows - kTile) / st + 1);
-        cg = std::min(cg, nyh);
-        const int c_ncby = ceil_div(nyh, cg);
         /* keep >= ~2k workgroups in flight: split the tile list when the
          * level has few candidate blocks */
-        const long blocks = (long)c_ncbx * c_ncby * n_theta_max * nq;
-        const int n_slices = blocks >= 4096 ? 1 : (int)std::min<long>(8, ceil_div(4096, (int)std::max<long>(1, blocks)));
+        const long blocks = (long)lp[h].ncb() * n_theta_max * nq;
+        const int n_slices =
+            blocks >= 2048 ? 1 : (int)std::min<long>(8, ceil_div(2048, (int)std::max<long>(1, blocks)));
         ScopedTimer tm(ctx, "score_coarse");
-        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[h]), nq, lstride, 1,
-                                     true, st, c_cbx, cg, c_ncbx * c_ncby, n_theta_max, n_slices)))
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[h]), nq, lp[h],
+                                     n_theta_max, n_slices)))
             return rc;
     }
     {
         ScopedTimer tm(ctx, "score_fine");
-        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lstride, R,
-                                     false, 1, cbx, groups, ncb, n_theta_max, 1)))
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0],
+                                     n_theta_max, 1)))
             return rc;
     }
     {

@@ -8,7 +8,8 @@
 namespace csm {
 
 constexpr int kTile = 64;        /* endpoint tile edge, cells */
-constexpr int kMaxRegionRows = 96; /* LDS region rows a workgroup may stage */
+constexpr int kMaxRegionRows = 96;         /* LDS region rows of a stride-1 job */
+constexpr int kMaxRegionRowsStrided = 128; /* ... of a strided (coarser level) job */
 constexpr int kPbMax = 1024;       /* beams per TileRec: k_bin splits fuller tiles */
 constexpr int kBlock = 256;      /* threads per workgroup (4 wave64) */
 constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
@@ -47,6 +48,8 @@ struct BinJob {
     const int32_t* hit_col;    /* [n_theta][n_points] */
     const int32_t* hit_row;
     uint32_t* sorted_pb;       /* [n_theta][n_points] packed LDS offsets */
+    uint32_t* sorted_rc;       /* optional: same order, (row << 16 | col) inside the
+                                  tile's bounding box, for strided jobs */
     TileRec*  tiles;           /* [n_theta][max_tiles] */
     int32_t*  n_tiles;         /* [n_theta] */
     uint32_t* flags;           /* [1] CSM_FLAG_* accumulated with atomicOr */
@@ -72,7 +75,9 @@ struct ScoreJob {
     int32_t n_theta, n_points, max_tiles;
     int32_t x_lo, y_lo;        /* cell offset of candidate index 0 */
     int32_t nx, ny;            /* candidates per axis */
-    int32_t stride;            /* cells between neighbouring candidates */
+    int32_t stride;            /* cells between neighbouring candidates (power of two
+                                  for the strided kernel) */
+    int32_t log2_stride;
     /* outputs (any may be null) */
     uint32_t*  dump_s;         /* [n_theta][nx][ny] */
     uint16_t*  dump_k;         /* [n_theta][nx][ny] */

@@ -165,8 +165,11 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             const int ty = rr / kTile, tx = cc / kTile;
             const int tile = ty * job.tiles_x + tx;
             const uint32_t pos = atomicAdd(&hist[tile], 1u);
-            out[pos] = (uint32_t)((rr - ty * kTile - (int)bb_rmin[tile]) * job.lstride +
-                                  (cc - tx * kTile - (int)bb_cmin[tile]));
+            const int rb = rr - ty * kTile - (int)bb_rmin[tile];
+            const int cb = cc - tx * kTile - (int)bb_cmin[tile];
+            out[pos] = (uint32_t)(rb * job.lstride + cb);
+            if (job.sorted_rc)
+                job.sorted_rc[(size_t)t * n + pos] = ((uint32_t)rb << 16) | (uint32_t)cb;
         }
     }
 }
@@ -203,8 +206,9 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 }
 
 /* LSTRIDE: LDS row pitch in cells. R: candidate rows per lane.
- * STRIDED: candidates are `stride` cells apart (coarser levels). */
-template <int LSTRIDE, int R, bool STRIDED>
+ * MODE 0: candidates one cell apart; 1: `stride` = 2^k cells apart (coarser
+ * levels); 2: any stride (e.g. LowResolutionMapWinSize 5). */
+template <int LSTRIDE, int R, int MODE>
 __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups,
                                            int slice, int n_slices)
 {
@@ -217,6 +221,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     if (t >= job.n_theta)
         return;
     const int tid = threadIdx.x;
+    constexpr bool STRIDED = MODE != 0;
     const int stride = STRIDED ? job.stride : 1;
     const int ncbx = (job.nx + cbx - 1) / cbx;
     const int bx = blockIdx.x % ncbx, by = blockIdx.x / ncbx;
@@ -233,14 +238,22 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     /* first candidate offset of this block, in cells */
     const int x0 = job.x_lo + bx * cbx * stride;
     const int y0 = job.y_lo + by * cby * stride;
-    /* LDS: one region of max_rows x LSTRIDE expanded cells (u32), then the
-     * beam offsets of the tile (kPbMax words) */
-    const int max_rows = kTile + (cby - 1) * stride;
+    /* LDS: one region of expanded cells (u32), then the beam offsets of the
+     * tile (kPbMax words). Stride-1 jobs keep the region row-major. Strided
+     * jobs (candidates 2^k cells apart) store it phase-major in both axes --
+     * region cell (rho, gamma) lives at row (rho mod s) * hd + rho div s,
+     * column (gamma mod s) * wd + gamma div s -- so that the candidates of one
+     * beam are contiguous again: conflict-free reads, R rows per lane. */
+    const int sh = MODE == 1 ? job.log2_stride : 0;
+    auto sdiv = [&](uint32_t x) { return MODE == 1 ? x >> sh : x / (uint32_t)stride; };
+    auto smod = [&](uint32_t x) { return MODE == 1 ? x & (uint32_t)(stride - 1) : x % (uint32_t)stride; };
+    const int hd = (kTile + stride - 1) / stride + cby - 1;   /* rows per row phase */
+    const int wd = LSTRIDE / stride;                          /* columns per column phase */
+    const int max_rows = STRIDED ? hd * stride : kTile + (cby - 1);
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb = sm_cells + max_rows * LSTRIDE;
     /* lane base inside the region (cells) */
-    const int tb = lane_on ? (g * R * stride) * LSTRIDE + dxi * stride : 0;
-    const int row_step = stride * LSTRIDE;
+    const int tb = lane_on ? (g * R) * LSTRIDE + dxi : 0;
     const int lane = tid & 63;
 
     /* acc packs (known count << 24) + (sum of values) of at most 255 beams;
@@ -269,7 +282,8 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)t * job.n_points;
     /* chunks (8 cells, 16 B of the uint16 grid) one lane may have to fetch per tile */
-    constexpr int kMaxCh = (kMaxRegionRows * (LSTRIDE / 8) + kBlock - 1) / kBlock;
+    constexpr int kMaxCh =
+        ((STRIDED ? kMaxRegionRowsStrided : kMaxRegionRows) * (LSTRIDE / 8) + kBlock - 1) / kBlock;
     constexpr int kPbRegs = kPbMax / kBlock;
 
     /* Software pipeline: the global loads of tile i+1 (cells and beam offsets)
@@ -343,9 +357,35 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                     hi4.y = expand(w.z >> 16);
                     hi4.z = expand(w.w & 0xffffu);
                     hi4.w = expand(w.w >> 16);
-                    uint4* dst = reinterpret_cast<uint4*>(sm_cells + lr * LSTRIDE + ch * 8);
-                    dst[0] = lo4;
-                    dst[1] = hi4;
+                    if (!STRIDED) {
+                        uint4* dst = reinterpret_cast<uint4*>(sm_cells + lr * LSTRIDE + ch * 8);
+                        dst[0] = lo4;
+                        dst[1] = hi4;
+                    } else {
+                        uint32_t* drow = sm_cells + (smod(lr) * hd + sdiv(lr)) * LSTRIDE;
+                        if (MODE == 1 && sh == 1) {
+                            /* stride 2: even cells -> phase 0, odd -> phase 1,
+                             * four consecutive dwords each */
+                            *reinterpret_cast<uint4*>(drow + ch * 4) =
+                                make_uint4(lo4.x, lo4.z, hi4.x, hi4.z);
+                            *reinterpret_cast<uint4*>(drow + wd + ch * 4) =
+                                make_uint4(lo4.y, lo4.w, hi4.y, hi4.w);
+                        } else if (MODE == 1 && sh == 2) {
+                            /* stride 4: cells j and j + 4 share phase j */
+                            *reinterpret_cast<uint2*>(drow + ch * 2) = make_uint2(lo4.x, hi4.x);
+                            *reinterpret_cast<uint2*>(drow + wd + ch * 2) = make_uint2(lo4.y, hi4.y);
+                            *reinterpret_cast<uint2*>(drow + 2 * wd + ch * 2) = make_uint2(lo4.z, hi4.z);
+                            *reinterpret_cast<uint2*>(drow + 3 * wd + ch * 2) = make_uint2(lo4.w, hi4.w);
+                        } else {
+                            const uint32_t e[8] = { lo4.x, lo4.y, lo4.z, lo4.w,
+                                                    hi4.x, hi4.y, hi4.z, hi4.w };
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const uint32_t gm = ch * 8 + j;
+                                drow[smod(gm) * wd + sdiv(gm)] = e[j];
+                            }
+                        }
+                    }
                 }
                 lr += dq;
                 ch += dr;
@@ -367,11 +407,17 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
         const int a = (cur.c0 + x0) & 7;
         const int cnt = (int)cur.count;
         const uint32_t* base = sm_cells + tb + a;
-        auto gather = [&](uint32_t off) {
-            const uint32_t* p = base + off;
+        auto gather = [&](uint32_t pbv) {
+            uint32_t off = pbv;
+            if (STRIDED) {
+                /* pbv = (row << 16 | col) inside the bounding box */
+                const uint32_t rb = pbv >> 16, cbm = (pbv & 0xffffu) + (uint32_t)a;
+                off = (smod(rb) * hd + sdiv(rb)) * LSTRIDE + smod(cbm) * wd + sdiv(cbm);
+            }
+            const uint32_t* p = (STRIDED ? sm_cells + tb : base) + off;
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                acc[r] += STRIDED ? p[r * row_step] : p[r * LSTRIDE];
+                acc[r] += p[r * LSTRIDE];
         };
         /* beam offsets: 64 per LDS read, broadcast with v_readlane */
         uint32_t pb_cur = lpb[lane];
@@ -494,18 +540,18 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
 }
 
 /* grid = (candidate blocks, theta slices, tile slices) */
-template <int LSTRIDE, int R, bool STRIDED>
+template <int LSTRIDE, int R, int MODE>
 __global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups)
 {
-    score_body<LSTRIDE, R, STRIDED>(job, cbx, groups, blockIdx.z, gridDim.z);
+    score_body<LSTRIDE, R, MODE>(job, cbx, groups, blockIdx.z, gridDim.z);
 }
 
 /* grid = (candidate blocks, theta slices, jobs * n_slices) */
-template <int LSTRIDE, int R, bool STRIDED>
+template <int LSTRIDE, int R, int MODE>
 __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups,
                                                        int n_slices)
 {
-    score_body<LSTRIDE, R, STRIDED>(jobs[blockIdx.z / n_slices], cbx, groups,
+    score_body<LSTRIDE, R, MODE>(jobs[blockIdx.z / n_slices], cbx, groups,
                                     blockIdx.z % n_slices, n_slices);
 }
 
