@@ -253,8 +253,9 @@ int  csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
                          csm_summary* out);
 
 /* ---- measurement hooks (bench.py) ---- */
-/* When enabled, every launch of the dominant scoring kernel is bracketed by
- * HIP events on the ctx stream. */
+/* enable = 1: every kernel launch is bracketed by HIP events on the ctx
+ * stream; enable = 2: only the dominant (fine-level) scoring kernel, to keep
+ * the timed region undisturbed; 0: off. */
 int  csm_enable_kernel_timing(csm_ctx* ctx, int32_t enable);
 /* Drains recorded events; returns total ms and launch count since the last
  * reset for kernel "score_fine" | "score_coarse" | "bin" | "finalize" | "boxmax". */

@@ -69,7 +69,10 @@ struct csm_ctx {
     DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
-    bool timing = false;
+    unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
+                                     clears the word of query i + 1 */
+    bool flags_ready = false;
+    int timing = 0;               /* 0 off, 1 every kernel, 2 the fine scoring kernel only */
     std::map<std::string, KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
 };
@@ -119,7 +122,7 @@ struct ScopedTimer {
     const char* name;
     ScopedTimer(csm_ctx* c, const char* n) : ctx(c), name(n)
     {
-        if (!ctx->timing)
+        if (!ctx->timing || (ctx->timing == 2 && std::strcmp(n, "score_fine") != 0))
             return;
         auto get = [&]() {
             hipEvent_t e = nullptr;
@@ -477,8 +480,14 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     if ((rc = ensure(ctx, ctx->best, nt * ncb * sizeof(BlockBest)))) return rc;
     if ((rc = ensure(ctx, ctx->sorted_rc, nt * p.n * 4))) return rc;
 
-    uint32_t* flags = reinterpret_cast<uint32_t*>(ctx->misc.p);
-    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 4, ctx->stream));
+    uint32_t* flag_words = reinterpret_cast<uint32_t*>(ctx->misc.p);
+    if (!ctx->flags_ready) {
+        HIP_TRY(ctx, hipMemsetAsync(flag_words, 0, 8, ctx->stream));
+        ctx->flags_ready = true;
+    }
+    uint32_t* flags = flag_words + (ctx->flag_toggle & 1u);
+    uint32_t* flags_next = flag_words + ((ctx->flag_toggle + 1u) & 1u);
+    ctx->flag_toggle++;
 
     BinJob bj;
     std::memset(&bj, 0, sizeof(bj));
@@ -506,6 +515,10 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         bj.band_win[0] = p.L;
         bj.band_nx[0] = p.nxc;
         bj.band_ny[0] = p.nyc;
+        /* the coarse pass accumulates with atomics: cleared here, per slice */
+        bj.zero_a = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
+        bj.zero_b = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
+        bj.zero_words = p.nxc * p.nyc;
     }
     {
         const size_t lds = (6 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4;
@@ -544,9 +557,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         cj.rank_l = 1;
         cj.skip_unless_band = w->min_known <= 1 && !force_coarse;
         const size_t nodes = nt * p.nxc * p.nyc;
+        (void)nodes;
         ScopedTimer tm(ctx, "score_coarse");
-        HIP_TRY(ctx, hipMemsetAsync(cj.acc_s, 0, nodes * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(cj.acc_k, 0, nodes * 4, ctx->stream));
         /* few candidates per slice: split the tile list over blockIdx.z so
          * enough workgroups are in flight to hide the staging latency */
         if ((rc = launch_score(ctx, cj, p.coarse, p.n_theta, kCoarseSlices)))
@@ -605,6 +617,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     fin.score_thr = w->score_threshold;
     fin.lut = ctx->lut_dev;
     fin.flags_in = flags;
+    fin.flags_clear = flags_next;
     fin.out = out_dev;
     {
         const size_t lds = (size_t)p.n * 8;
@@ -1826,7 +1839,7 @@ int csm_enable_kernel_timing(csm_ctx* ctx, int32_t enable)
 {
     if (!ctx)
         return CSM_EINVAL;
-    ctx->timing = enable != 0;
+    ctx->timing = enable;
     return CSM_OK;
 }
 

@@ -53,6 +53,9 @@ struct BinJob {
     TileRec*  tiles;           /* [n_theta][max_tiles] */
     int32_t*  n_tiles;         /* [n_theta] */
     uint32_t* flags;           /* [1] CSM_FLAG_* accumulated with atomicOr */
+    uint32_t* zero_a;          /* optional: [n_theta][zero_words] arrays this kernel clears */
+    uint32_t* zero_b;          /*   (the coarse level's atomic accumulators)                */
+    int32_t   zero_words;
     int32_t n_theta, n_points, max_tiles;
     int32_t rows, cols;
     int32_t x_lo, y_lo;        /* most negative candidate offset */
@@ -121,6 +124,7 @@ struct FinalJob {
     double score_thr;
     const double* lut;
     const uint32_t* flags_in;
+    uint32_t* flags_clear;     /* optional: the flag word of the NEXT query, cleared here */
     void* out;                 /* csm_result* (device) */
 };
 

@@ -77,6 +77,11 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int32_t* col = job.hit_col + (size_t)t * n;
     const int32_t* row = job.hit_row + (size_t)t * n;
 
+    if (job.zero_a)
+        for (int i = tid; i < job.zero_words; i += kBlock) {
+            job.zero_a[(size_t)t * job.zero_words + i] = 0;
+            job.zero_b[(size_t)t * job.zero_words + i] = 0;
+        }
     for (int i = tid; i < ntile; i += kBlock) {
         hist[i] = 0;
         bb_rmin[i] = kTile;
@@ -122,16 +127,34 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     part[tid] = cnt;
     part[kBlock + tid] = ne;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t a = 0, b = 0;
-        for (int i = 0; i < kBlock; ++i) {
-            const uint32_t x = part[i], y = part[kBlock + i];
-            part[i] = a;
-            part[kBlock + i] = b;
-            a += x;
-            b += y;
+    {
+        /* exclusive scan over the kBlock partials: wave64 shuffles, then the
+         * four wave totals */
+        uint32_t a = cnt, b = ne;
+        const int ln = tid & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
+            if (ln >= d) {
+                a += ua;
+                b += ub;
+            }
         }
-        job.n_tiles[t] = (int32_t)b;
+        __shared__ uint32_t wtot[2][kBlock / 64];
+        if (ln == 63) {
+            wtot[0][tid >> 6] = a;
+            wtot[1][tid >> 6] = b;
+        }
+        __syncthreads();
+        uint32_t ba = 0, bb2 = 0;
+        for (int w = 0; w < (tid >> 6); ++w) {
+            ba += wtot[0][w];
+            bb2 += wtot[1][w];
+        }
+        part[tid] = ba + a - cnt;
+        part[kBlock + tid] = bb2 + b - ne;
+        if (tid == kBlock - 1)
+            job.n_tiles[t] = (int32_t)(bb2 + b);
     }
     __syncthreads();
     uint32_t off = part[tid], slot = part[kBlock + tid];
@@ -626,6 +649,8 @@ __device__ __forceinline__ void k_finalize_body(const FinalJob& job)
 
     csm_result* out = reinterpret_cast<csm_result*>(job.out);
     const uint32_t flags_in = job.flags_in ? (*job.flags_in & 0xffffu) : 0u;
+    if (job.flags_clear && tid == 0)
+        *job.flags_clear = 0u;
     if (bkey == 0) {
         if (tid == 0) {
             csm_result r;
@@ -667,8 +692,15 @@ __device__ __forceinline__ void k_finalize_body(const FinalJob& job)
         s += v;
         k += v != 0;
     }
-    red_s[tid] = s;
-    red_k[tid] = k;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s += __shfl_xor(s, m, 64);
+        k += __shfl_xor(k, m, 64);
+    }
+    if ((tid & 63) == 0) {
+        red_s[tid >> 6] = s;
+        red_k[tid >> 6] = k;
+    }
     __syncthreads();
     if (tid == 0) {
         /* beam order, one rounding per add; adding the 0.0 of an unknown
@@ -687,7 +719,7 @@ __device__ __forceinline__ void k_finalize_body(const FinalJob& job)
         for (; i < job.n_points; ++i)
             sum += sm_p[i];
         uint32_t st = 0, kt = 0;
-        for (int i = 0; i < kBlock; ++i) {
+        for (int i = 0; i < kBlock / 64; ++i) {
             st += red_s[i];
             kt += red_k[i];
         }
