@@ -119,3 +119,31 @@ class LoopDetectorBranchBoundHIP:
         records = bytes_to_records(allrec)
         found = [i for i, r in enumerate(records) if r["found"]]
         return records, found
+
+
+class LoopDetectorCorrelativeHIP:
+    """Search part of LoopDetectorCorrelative::Detect
+    (src/my_lidar_graph_slam/mapping/loop_detector_correlative.cpp:59-156): the
+    correlative matcher with a coarse map cached per local-map id and the
+    detector's two thresholds, one query after the other."""
+
+    def __init__(self, name, ctx, low_resolution, range_x, range_y, range_theta,
+                 score_threshold, known_rate_threshold):
+        self.name = name
+        self.ctx = ctx
+        self.low_resolution = low_resolution
+        self.ranges = (range_x, range_y, range_theta)
+        self.score_threshold = score_threshold
+        self.known_rate_threshold = known_rate_threshold
+
+    def detect(self, queries, grids=None):
+        """Returns (summaries in query order, indices of the found ones)."""
+        outs = []
+        for q in queries:
+            if not self.ctx.has_grid(q["map_id"]):
+                self.ctx.upload_grid(q["map_id"], grids[q["map_id"]])
+            outs.append(self.ctx.correlative_match(
+                q["map_id"], q["geom"], q["angles"], q["ranges"], q["rel_pose"], q["init_pose"],
+                self.ranges[0], self.ranges[1], self.ranges[2], self.low_resolution,
+                self.score_threshold, self.known_rate_threshold))
+        return outs, [i for i, o in enumerate(outs) if o["pose_found"]]

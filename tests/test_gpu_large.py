@@ -1,0 +1,92 @@
+"""GPU tests at BASELINE's large sizes, through properties that need no full
+CPU oracle run, plus the LoopDetectorCorrelative wrapper (default L = 5)."""
+import math
+
+import numpy as np
+import pytest
+
+from csm_hip import api, parallel, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_exhaustive_global_window(gpu_ctx, oracle):
+    """configs[4]: 2000x2000 grid @ 2.5 cm, +-10 m / +-180 deg at 2.5 cm / 0.25 deg,
+    1080 beams, L = 4: 1441 x 804 x 804 = 9.3e8 candidate poses (2.0 TB of
+    algorithmic gathers). Checked: window arithmetic, the winner's exact f64
+    score and integer sums against the oracle's Score() at that pose, that no
+    candidate of a 3x3x3 neighbourhood + 2000 random ones scores higher
+    (oracle, including the offset nearest to the pose the scan was cast from --
+    the room is symmetric and most beams are range-clipped, so the global
+    optimum need not be that pose), idempotence."""
+    case = synth.csm_case(7, rows=2000, cols=2000, res=0.025, n_beams=1080, fov=1.5 * math.pi,
+                          max_range=5.7296, init_error=(3.1, -2.7, 1.3), n_boxes=10)
+    rx, ry, rt, L = 20.0, 20.0, 2 * math.pi, 4
+    m = api.ScanMatcherCorrelativeHIP("cfg5", L, rx, ry, rt, ctx=gpu_ctx)
+    out = m.optimize_pose(case["grid"], case["geom"], case["angles"], case["ranges"],
+                          case["rel_pose"], case["init_pose"], map_id=555)
+    raw = out["raw"]
+    assert (out["win_x"], out["win_y"]) == (400, 400)
+    assert out["win_theta"] == api.host_window(rt, out["step_theta"])
+    assert out["candidates"] == (2 * out["win_theta"] + 1) * 804 * 804
+    assert out["pose_found"] == 1
+    # exact score of the winner
+    s, known = oracle.score_at(case["grid"], case["geom"], case["angles"], case["ranges"],
+                               out["best_sensor_pose"])
+    assert raw["score"] == s
+    assert raw["known"] == known
+    assert raw["key"] == 32268 * raw["known"] + 499 * raw["sum_values"]
+    # nothing nearby or at random beats it (integer offsets: CSM projection)
+    sx, sy, st = out["step_x"], out["step_y"], out["step_theta"]
+    rng = np.random.RandomState(0)
+    cands = [(dx, dy, dt) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dt in (-1, 0, 1)]
+    cands += [(int(rng.randint(-400, 404)) - raw["best_x"], int(rng.randint(-400, 404)) - raw["best_y"],
+               int(rng.randint(-out["win_theta"], out["win_theta"] + 1)) - raw["best_theta"])
+              for _ in range(300)]
+    # the offset nearest to the true pose
+    truth = np.asarray(case["truth"])
+    tx = int(round((truth[0] - out["sensor_pose"][0]) / sx)) - raw["best_x"]
+    ty = int(round((truth[1] - out["sensor_pose"][1]) / sy)) - raw["best_y"]
+    tt = int(round((truth[2] - out["sensor_pose"][2]) / st)) - raw["best_theta"]
+    cands.append((tx, ty, tt))
+    for dx, dy, dt in cands:
+        t = raw["best_theta"] + dt
+        pose_t = (out["sensor_pose"][0], out["sensor_pose"][1], out["sensor_pose"][2] + st * t)
+        col, row = oracle.project(case["geom"], pose_t, case["angles"], case["ranges"])
+        r = row + raw["best_y"] + dy
+        c = col + raw["best_x"] + dx
+        ok = (r >= 0) & (r < 2000) & (c >= 0) & (c < 2000)
+        v = np.where(ok, case["grid"][np.clip(r, 0, 1999), np.clip(c, 0, 1999)], 0).astype(np.int64)
+        key = 32268 * int((v != 0).sum()) + 499 * int(v.sum())
+        assert key <= raw["key"]
+    again = m.optimize_pose(None, case["geom"], case["angles"], case["ranges"], case["rel_pose"],
+                            case["init_pose"], map_id=555)
+    assert again["raw"] == raw
+    gpu_ctx.release_grid(555)
+
+
+def test_loop_detector_correlative_default_settings(gpu_ctx, oracle):
+    """LoopDetectorCorrelative with the reference's default settings
+    (launcher_settings_default.json:101-114: L = 5, 2.5 m x 2.5 m x 0.5 rad,
+    thresholds 0.55 / 0.6 -- lowered here so that some queries are found)."""
+    cases = [synth.csm_case(110 + i, n_beams=720, init_error=(0.5, -0.4, 0.08)) for i in range(5)]
+    queries, grids = [], {}
+    for i, c in enumerate(cases):
+        grids[700 + i] = c["grid"]
+        queries.append(dict(map_id=700 + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+                            rel_pose=c["rel_pose"], init_pose=c["init_pose"]))
+    det = parallel.LoopDetectorCorrelativeHIP("ldc", gpu_ctx, 5, 2.5, 2.5, 0.5, 0.35, 0.6)
+    outs, found = det.detect(queries, grids)
+    want_found = []
+    for i, (c, o) in enumerate(zip(cases, outs)):
+        lit = oracle.csm(c, 2.5, 2.5, 0.5, 5, 0.35, 0.6)
+        assert o["pose_found"] == lit["found"]
+        assert (o["raw"]["best_x"], o["raw"]["best_y"], o["raw"]["best_theta"]) == \
+            (lit["bestX"], lit["bestY"], lit["bestT"])
+        assert o["raw"]["score"] == lit["scoreMax"]
+        assert o["estimated_pose"] == lit["estimatedPose"]
+        if lit["found"]:
+            want_found.append(i)
+    assert found == want_found
+    for k in grids:
+        gpu_ctx.release_grid(k)

@@ -75,6 +75,27 @@ def main():
         leaves_per_s_cached=leaves / t_cached,
         kernel_ms={k: v[0] for k, v in kt.items()},
         device_only_leaves_per_s=leaves / (sum(v[0] for v in kt.values()) * 1e-3))
+    # config 5: exhaustive global window on a 2000 x 2000 grid
+    for k in grids:
+        ctx.release_grid(k)
+    big = synth.csm_case(7, rows=2000, cols=2000, res=0.025, n_beams=1080, fov=1.5 * math.pi,
+                         max_range=5.7296, init_error=(3.1, -2.7, 1.3), n_boxes=10)
+    ctx.upload_grid(9, big["grid"])
+    m5 = api.ScanMatcherCorrelativeHIP("e2e5", 4, 20.0, 20.0, 2 * math.pi, ctx=ctx)
+    r = m5.optimize_pose(None, big["geom"], big["angles"], big["ranges"], big["rel_pose"],
+                         big["init_pose"], map_id=9)
+    ctx.enable_kernel_timing(True)
+    ctx.reset_kernel_timing()
+    t0 = time.perf_counter()
+    r = m5.optimize_pose(None, big["geom"], big["angles"], big["ranges"], big["rel_pose"],
+                         big["init_pose"], map_id=9)
+    dt = time.perf_counter() - t0
+    kt = {k: ctx.kernel_time(k) for k in ("project", "bin", "score_coarse", "score_fine", "finalize")}
+    out["config5_global_window"] = dict(
+        s_per_call=dt, candidates=r["candidates"], poses_per_s=r["candidates"] / dt,
+        algorithmic_TB=r["candidates"] * 2160 / 1e12, kernel_ms={k: v[0] for k, v in kt.items()},
+        fine_algorithmic_GBs=r["candidates"] * 2160 / (kt["score_fine"][0] * 1e-3) / 1e9,
+        flags=r["raw"]["flags"], found=r["pose_found"])
     print(json.dumps(out, indent=1))
 
 
