@@ -1,0 +1,89 @@
+"""GPU tests of the C ABI's contract: error codes instead of crashes, the
+device-resident entry points, cached pyramids, the timing hooks."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from csm_hip import _lib as L
+from csm_hip import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_error_codes_not_crashes(gpu_ctx):
+    lib = gpu_ctx.lib
+    ctx = gpu_ctx._ctx
+    out = np.zeros((4, 4), np.uint16)
+    assert lib.csm_download_level(ctx, 424242, 0, out.ctypes.data_as(C.c_void_p)) == L.CSM_ENOENT
+    assert b"not resident" in lib.csm_last_error(ctx)
+    assert lib.csm_release_grid(ctx, 424242) == L.CSM_ENOENT
+    assert lib.csm_upload_grid(ctx, 1, None, 4, 4) == L.CSM_EINVAL
+    g = np.zeros((16, 16), np.uint16)
+    gpu_ctx.upload_grid(31, g)
+    w = np.array([1, 64], np.int32)      # window larger than the grid
+    assert lib.csm_build_pyramid(ctx, 31, w.ctypes.data_as(C.POINTER(C.c_int32)), 2) == L.CSM_EINVAL
+    w = np.array([2, 1], np.int32)       # level 0 must be the grid itself
+    assert lib.csm_build_pyramid(ctx, 31, w.ctypes.data_as(C.POINTER(C.c_int32)), 2) == L.CSM_EINVAL
+    win = gpu_ctx.make_window(3, 8, 2, 2, 2, 5, 1, 0.0)   # coarse level 5 does not exist
+    col = np.zeros((3, 8), np.int32)
+    res = L.Result()
+    rc = lib.csm_score_window(ctx, 31, C.byref(win), col.ctypes.data_as(C.c_void_p),
+                              col.ctypes.data_as(C.c_void_p), C.byref(res))
+    assert rc == L.CSM_ENOENT
+    gpu_ctx.release_grid(31)
+    assert not gpu_ctx.has_grid(31)
+    with pytest.raises(api.CsmError):
+        gpu_ctx.bnb_match_batch([dict(map_id=99999, geom=(0.05, 0, 0), angles=[0.0], ranges=[1.0],
+                                      rel_pose=(0, 0, 0), init_pose=(0, 0, 0))], 1, 1, 0.1, 2, 0.5, 0.5)
+
+
+def test_device_resident_window_and_timing_hooks(gpu_ctx, oracle):
+    """csm_score_window_dev on torch-owned device memory, on torch's stream,
+    then csm_resolve_window_dev; the per-kernel event timers fill in."""
+    case = synth.csm_case(8, levels=3, interior_unknown=0.0)        # tie-prone map
+    rx, ry, rt, Lr = 1.0, 1.0, math.radians(10), 4
+    sx, sy, st = api.host_search_step(case["geom"][0], case["ranges"])
+    wx, wy, wt = api.host_window(rx, sx), api.host_window(ry, sy), api.host_window(rt, st)
+    col, row = api.host_project(case["geom"], case["init_pose"], st, wt, case["angles"], case["ranges"])
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.upload_grid(5, case["grid"])
+    ctx.build_pyramid(5, [1, Lr])
+    w = ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, Lr, 1, 1, 0.0)
+    c_d, r_d = torch.from_numpy(col).to(dev), torch.from_numpy(row).to(dev)
+    out_d = torch.zeros(48, dtype=torch.uint8, device=dev)
+    ctx.enable_kernel_timing(True)
+    ctx.score_window_dev(5, w, c_d.data_ptr(), r_d.data_ptr(), out_d.data_ptr())
+    rc = ctx.lib.csm_resolve_window_dev(ctx._ctx, 5, C.byref(w), C.c_void_p(c_d.data_ptr()),
+                                        C.c_void_p(r_d.data_ptr()), C.c_void_p(out_d.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize(dev)
+    rec = L.Result.from_buffer_copy(out_d.cpu().numpy().tobytes())
+    lit = oracle.csm(case, rx, ry, rt, Lr)
+    assert (rec.best_x, rec.best_y, rec.best_theta) == (lit["bestX"], lit["bestY"], lit["bestT"])
+    assert rec.score == lit["scoreMax"]
+    ms, n = ctx.kernel_time("score_fine")
+    assert n >= 1 and ms > 0
+    assert ctx.kernel_time("bin")[1] >= 1
+    ctx.reset_kernel_timing()
+    assert ctx.kernel_time("score_fine") == (0.0, 0)
+    ctx.close()
+
+
+def test_pyramid_is_cached_per_map_id(gpu_ctx, oracle):
+    case = synth.csm_case(9)
+    gpu_ctx.upload_grid(77, case["grid"])
+    q = dict(map_id=77, geom=case["geom"], angles=case["angles"], ranges=case["ranges"],
+             rel_pose=case["rel_pose"], init_pose=case["init_pose"])
+    a = gpu_ctx.bnb_match_batch([q], 2.5, 2.5, 0.5, 3, 0.3, 0.5)[0]
+    b = gpu_ctx.bnb_match_batch([q, q], 2.5, 2.5, 0.5, 3, 0.3, 0.5)
+    assert a["raw"] == b[0]["raw"] == b[1]["raw"]
+    assert b[0]["input_setup_us"] < a["input_setup_us"] or a["input_setup_us"] < 2000
+    # levels 1, 2, 4, 8 exist and match the oracle
+    for lvl, win in enumerate([1, 2, 4, 8]):
+        assert np.array_equal(gpu_ctx.download_level(77, lvl), oracle.boxmax(case["grid"], win))
+    gpu_ctx.release_grid(77)
