@@ -41,6 +41,7 @@ struct Level {
 
 struct DeviceGrid {
     int rows = 0, cols = 0, pitch = 0;
+    int known_r0 = 0, known_c0 = 0;   /* first row / column holding a known cell */
     std::vector<Level> levels;   /* levels[0] is the uploaded grid */
 };
 
@@ -508,6 +509,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.y_hi = p.y_hi;
     bj.tiles_x = p.tiles_x;
     bj.tiles_y = p.tiles_y;
+    bj.known_r0 = g.known_r0;
+    bj.known_c0 = g.known_c0;
     bj.lstride = p.fine.lstride;
     bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
     if (p.L > 1) {
@@ -872,6 +875,20 @@ int csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense, int32_
     g.rows = rows;
     g.cols = cols;
     g.pitch = (cols + 7) & ~7;
+    /* first known row / column (tightens the edge-band test of k_bin) */
+    g.known_r0 = rows;
+    g.known_c0 = cols;
+    for (int r = 0; r < rows; ++r) {
+        const uint16_t* line = dense + (size_t)r * cols;
+        for (int c = 0; c < cols; ++c)
+            if (line[c] != 0) {
+                if (r < g.known_r0)
+                    g.known_r0 = r;
+                if (c < g.known_c0)
+                    g.known_c0 = c;
+                break;          /* later cells of this row cannot lower known_c0 below c */
+            }
+    }
     Level base;
     const size_t bytes = (size_t)rows * g.pitch * 2;
     if (hipMalloc(reinterpret_cast<void**>(&base.cells), bytes) != hipSuccess) {
@@ -1616,6 +1633,8 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         B.y_hi = y_lo + ny - 1;
         B.tiles_x = p.tiles_x;
         B.tiles_y = p.tiles_y;
+        B.known_r0 = g.known_r0;
+        B.known_c0 = g.known_c0;
         B.lstride = lstride;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {
@@ -1648,6 +1667,10 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
             S.ny = ny >> h;
             S.stride = 1 << h;
             S.log2_stride = h;
+            /* a leaf's own known count bounds every ancestor's from below when
+             * no read can fall in the edge band: the level passes are only
+             * needed to detect (and then handle) that case */
+            S.skip_unless_band = 1;
             S.sorted_pb = B.sorted_rc;
             S.acc_s = d_lvl_s + p.lvl_off[h];
             S.acc_k = d_lvl_k + p.lvl_off[h];
@@ -1660,6 +1683,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         F.stride = 1;
         F.block_best = d_best + p.best_off;
         F.check_own_known = 1;
+        F.elig_only_if_band = 1;
         F.n_elig = H;
         for (int h = 1; h <= H; ++h) {
             F.elig[h - 1].k = d_lvl_k + p.lvl_off[h];

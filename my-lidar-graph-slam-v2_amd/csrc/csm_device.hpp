@@ -62,6 +62,9 @@ struct BinJob {
     int32_t x_hi, y_hi;        /* most positive candidate offset */
     int32_t tiles_x, tiles_y;
     int32_t lstride;
+    /* first row / column of the map that holds a known cell: a box that ends
+     * before it is unknown on every level, so reading it as unknown is right */
+    int32_t known_r0, known_c0;
     /* edge-band detection: coarse strides to test (box windows) */
     int32_t n_band;
     int32_t band_win[kMaxElig];
@@ -126,22 +129,6 @@ struct FinalJob {
     const uint32_t* flags_in;
     uint32_t* flags_clear;     /* optional: the flag word of the NEXT query, cleared here */
     void* out;                 /* csm_result* (device) */
-};
-
-/* Branch-and-bound projection: per (theta, beam) products r*cos / r*sin come
- * from the host (glibc), the device derives the base cell indices and checks
- * that every per-node projection equals base + offset. */
-struct IndexJob {
-    const double* r_cos;       /* [n_theta][n_points] */
-    const double* r_sin;
-    int32_t* hit_col;          /* [n_theta][n_points] out */
-    int32_t* hit_row;
-    uint32_t* flags;           /* [1] CSM_FLAG_PROJ_DELTA */
-    int32_t n_theta, n_points;
-    int32_t x_lo, y_lo, nx, ny;
-    double sensor_x, sensor_y;
-    double step_x, step_y;
-    double off_x, off_y, res;
 };
 
 /* Device-side projection with a certificate. The device evaluates

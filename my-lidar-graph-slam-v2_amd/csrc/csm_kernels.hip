@@ -40,14 +40,17 @@ __device__ __forceinline__ int floor_div(int a, int b)
     return q;
 }
 
-/* Is there k in [0, nk) with -(w-1) <= u + k*w <= -1 ?  Returns k or -1. */
-__device__ __forceinline__ int band_index(int u, int w, int nk)
+/* Is there k in [0, nk) with -(w-1) <= v = u + k*w <= -1 (a coarse read in the
+ * negative edge band) whose box [v, v + w) reaches the first known row /
+ * column `known_lo` of the map? Only then can the coarse level read "unknown"
+ * where the box maximum is known. */
+__device__ __forceinline__ bool band_hit(int u, int w, int nk, int known_lo)
 {
     const int k0 = floor_div(-u, w);
     if (k0 < 0 || k0 >= nk)
-        return -1;
+        return false;
     const int v = u + k0 * w;
-    return (v <= -1 && v >= -(w - 1)) ? k0 : -1;
+    return v <= -1 && v >= -(w - 1) && v + w - 1 >= known_lo;
 }
 
 /* PositionToIndex on device, IEEE double, no contraction: bit-identical to
@@ -107,8 +110,8 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         }
         for (int b = 0; b < job.n_band; ++b) {
             const int w = job.band_win[b];
-            if (band_index(r + job.y_lo, w, job.band_ny[b]) >= 0 ||
-                band_index(c + job.x_lo, w, job.band_nx[b]) >= 0)
+            if (band_hit(r + job.y_lo, w, job.band_ny[b], job.known_r0) ||
+                band_hit(c + job.x_lo, w, job.band_nx[b], job.known_c0))
                 band = true;
         }
     }
@@ -974,21 +977,6 @@ __global__ __launch_bounds__(kBlock) void k_finalize_batch(const FinalJob* jobs)
     k_finalize_body(jobs[blockIdx.x]);
 }
 
-/* Does floor((hit - off) / res) equal `expect`? Cheap certified test first
- * (multiply by the reciprocal, margin far above its rounding error), exact
- * division only next to a cell edge. */
-__device__ __forceinline__ bool index_is(double hit, double off, double res, double inv_res,
-                                         int expect)
-{
-    const double t = hit - off;
-    const double q = t * inv_res;
-    const double e = (double)expect;
-    const double margin = 1e-9 * (fabs(e) + 1.0);
-    if (q > e + margin && q < e + 1.0 - margin)
-        return true;
-    return (int)floor(t / res) == expect;
-}
-
 /* Bound on |q_host - q_device| for q = (sensor + r*trig - off) / res, in
  * cells: 3 ulp between the two libms on the trig value, one rounding per
  * arithmetic step on either side; the caller multiplies by a safety factor. */
@@ -1061,40 +1049,6 @@ __global__ __launch_bounds__(kBlock) void k_project(ProjJob job)
 __global__ __launch_bounds__(kBlock) void k_project_batch(const ProjJob* jobs)
 {
     proj_body(jobs[blockIdx.z]);
-}
-
-__global__ __launch_bounds__(kBlock) void k_bnb_index(const IndexJob* jobs)
-{
-    const IndexJob& job = jobs[blockIdx.z];
-    const int t = blockIdx.y;
-    if (t >= job.n_theta)
-        return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= job.n_points)
-        return;
-    const size_t idx = (size_t)t * job.n_points + i;
-    const double rc = job.r_cos[idx], rs = job.r_sin[idx];
-    /* ScanData::HitPoint at the un-shifted sensor pose */
-    const int col = cell_index(job.sensor_x + rc, job.off_x, job.res);
-    const int row = cell_index(job.sensor_y + rs, job.off_y, job.res);
-    job.hit_col[idx] = col;
-    job.hit_row[idx] = row;
-    /* appendNode's pose: sensor + x * step, then HitPoint, then PositionToIndex
-     * (src/mapping/scan_matcher_branch_bound.cpp:156-176) */
-    const double inv_res = 1.0 / job.res;
-    bool delta = false;
-    for (int xi = 0; xi < job.nx; ++xi) {
-        const int x = job.x_lo + xi;
-        const double px = job.sensor_x + x * job.step_x;
-        delta |= !index_is(px + rc, job.off_x, job.res, inv_res, col + x);
-    }
-    for (int yi = 0; yi < job.ny; ++yi) {
-        const int y = job.y_lo + yi;
-        const double py = job.sensor_y + y * job.step_y;
-        delta |= !index_is(py + rs, job.off_y, job.res, inv_res, row + y);
-    }
-    if (delta)
-        atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
 }
 
 } /* namespace csm */
