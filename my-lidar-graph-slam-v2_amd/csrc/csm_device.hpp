@@ -8,10 +8,10 @@
 namespace csm {
 
 constexpr int kTile = 64;        /* endpoint tile edge, cells */
-constexpr int kMaxRegionRows = 96;         /* LDS region rows of a stride-1 job */
+constexpr int kMaxRegionRows = 128;        /* LDS region rows of a stride-1 job */
 constexpr int kMaxRegionRowsStrided = 128; /* ... of a strided (coarser level) job */
 constexpr int kPbMax = 1024;       /* beams per TileRec: k_bin splits fuller tiles */
-constexpr int kBlock = 256;      /* threads per workgroup (4 wave64) */
+constexpr int kBlock = 512;      /* threads per workgroup (8 wave64) */
 constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
 /* internal flag bit (never returned): some beam can reach the negative edge
  * band of a coarser level for some candidate offset */
