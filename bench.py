@@ -97,19 +97,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CSM_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend, to walk
+    # the multi-process control flow on a one-GPU box (numbers meaningless)
+    rehearse = os.environ.get("CSM_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
-    ge.build()
+    ge.build()          # file-locked: ranks take turns, later ones find it built
     from csm_hip import api, _lib
 
     wl = make_workload(rank, SCANS_PER_STEP)
     rx, ry, rt, L = wl["params"]
-    ctx = api.Context(local_rank)
+    ctx = api.Context(dev_index)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.upload_grid(1, wl["grid"])
@@ -136,7 +143,12 @@ def main():
             ctx.score_window_dev(1, windows[i], cols[i].data_ptr(), rows_[i].data_ptr(),
                                  results.data_ptr() + i * rec_bytes)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, results)
+            if rehearse:
+                host = results.cpu()
+                out = torch.zeros(world * host.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, host)
+            else:
+                dist.all_gather_into_tensor(gathered, results)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -168,7 +180,7 @@ def main():
     fin_ms, fin_n = ctx.kernel_time("finalize")
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -258,6 +258,19 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
     return true;
 }
 
+/* Two LDS buffers (one barrier per tile, staging overlapped with the gather)
+ * when they fit; CSM_NBUF overrides for tuning. */
+int pick_buffers(size_t lds_one, long blocks)
+{
+    (void)blocks;
+    const char* force = getenv("CSM_NBUF");
+    if (force)
+        return atoi(force) == 2 && 2 * lds_one <= 160 * 1024 - 256 ? 2 : 1;
+    /* measured (512-thread workgroups): no gain on config 2, and the halved
+     * occupancy costs 25-35 % on configs 3 and 5 */
+    return 1;
+}
+
 size_t pass_lds_bytes(const PassPlan& p)
 {
     const int cby = p.groups * p.R;
@@ -350,7 +363,7 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         if (rc_)                                                                       \
             return rc_;                                                                \
         hipLaunchKernelGGL((k_score<LS, RR, ST>), grid, dim3(kBlock), lds, ctx->stream, \
-                           job, pp.cbx, pp.groups);                                    \
+                           job, pp.cbx, pp.groups, n_buf);                             \
     } while (0)
 
 #define CALL_BATCH(LS, RR, ST)                                                         \
@@ -359,16 +372,18 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         if (rc_)                                                                       \
             return rc_;                                                                \
         hipLaunchKernelGGL((k_score_batch<LS, RR, ST>), grid, dim3(kBlock), lds,       \
-                           ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices);        \
+                           ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices, n_buf); \
     } while (0)
 
 int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta, int n_slices)
 {
     const dim3 grid(pp.ncb(), n_theta, n_slices);
     const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
-    const size_t lds = pass_lds_bytes(pp);
+    size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
+    const int n_buf = pick_buffers(lds, (long)grid.x * grid.y * grid.z);
+    lds *= n_buf;
     bool launched = false;
     SCORE_DISPATCH(CALL_SINGLE);
     if (!launched)
@@ -382,9 +397,11 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
 {
     const dim3 grid(pp.ncb(), n_theta_max, n_jobs * n_slices);
     const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
-    const size_t lds = pass_lds_bytes(pp);
+    size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
+    const int n_buf = pick_buffers(lds, (long)grid.x * grid.y * grid.z);
+    lds *= n_buf;
     bool launched = false;
     SCORE_DISPATCH(CALL_BATCH);
     if (!launched)

@@ -236,7 +236,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
  * levels); 2: any stride (e.g. LowResolutionMapWinSize 5). */
 template <int LSTRIDE, int R, int MODE>
 __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups,
-                                           int slice, int n_slices)
+                                           int slice, int n_slices, int n_buf)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
     __shared__ unsigned long long red_key[kBlock / 64];
@@ -276,6 +276,9 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     const int hd = (kTile + stride - 1) / stride + cby - 1;   /* rows per row phase */
     const int wd = LSTRIDE / stride;                          /* columns per column phase */
     const int max_rows = STRIDED ? hd * stride : kTile + (cby - 1);
+    /* n_buf == 2: two (region + beam offset) buffers used alternately, one
+     * barrier per tile; n_buf == 1: one buffer, two barriers per tile */
+    const int buf_words = max_rows * LSTRIDE + kPbMax;
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb = sm_cells + max_rows * LSTRIDE;
     /* lane base inside the region (cells) */
@@ -366,8 +369,13 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
         rec = recs[ti];
         fetch(rec);
     }
-    for (; ti < ntiles; ti += n_slices) {
-        __syncthreads();                             /* previous tile consumed */
+    for (int it = 0; ti < ntiles; ti += n_slices, ++it) {
+        if (n_buf == 1) {
+            __syncthreads();                         /* previous tile consumed */
+        } else {
+            sm_cells = reinterpret_cast<uint32_t*>(sm_tile) + (it & 1) * buf_words;
+            lpb = sm_cells + max_rows * LSTRIDE;
+        }
         {
             int lr = lr0, ch = ch0;
 #pragma unroll
@@ -567,18 +575,18 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
 
 /* grid = (candidate blocks, theta slices, tile slices) */
 template <int LSTRIDE, int R, int MODE>
-__global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups)
+__global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups, int n_buf)
 {
-    score_body<LSTRIDE, R, MODE>(job, cbx, groups, blockIdx.z, gridDim.z);
+    score_body<LSTRIDE, R, MODE>(job, cbx, groups, blockIdx.z, gridDim.z, n_buf);
 }
 
 /* grid = (candidate blocks, theta slices, jobs * n_slices) */
 template <int LSTRIDE, int R, int MODE>
 __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups,
-                                                       int n_slices)
+                                                       int n_slices, int n_buf)
 {
     score_body<LSTRIDE, R, MODE>(jobs[blockIdx.z / n_slices], cbx, groups,
-                                    blockIdx.z % n_slices, n_slices);
+                                    blockIdx.z % n_slices, n_slices, n_buf);
 }
 
 /* ------------------------------------------------------------------ K2 */
