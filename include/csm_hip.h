@@ -252,6 +252,14 @@ int  csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
                          int32_t n_queries, const csm_bnb_params* params,
                          csm_summary* out);
 
+/* LoopDetectorCorrelative::Detect's search part for a batch of queries
+ * (src/mapping/loop_detector_correlative.cpp:59-156, lines 68-108): the
+ * correlative matcher with the detector's thresholds against resident maps,
+ * one coarse map (box-max L) cached per map id. out[i] <-> queries[i]. */
+int  csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
+                                 int32_t n_queries, const csm_correlative_params* params,
+                                 csm_summary* out);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* enable = 1: every kernel launch is bracketed by HIP events on the ctx
  * stream; enable = 2: only the dominant (fine-level) scoring kernel, to keep

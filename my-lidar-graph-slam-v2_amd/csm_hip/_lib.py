@@ -125,6 +125,8 @@ SIGNATURES = {
                                         C.c_void_p, _P(CorrelativeParams), _P(Summary)]),
     "csm_bnb_match_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32,
                                       _P(BnbParams), _P(Summary)]),
+    "csm_correlative_match_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32,
+                                              _P(CorrelativeParams), _P(Summary)]),
     "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),
     "csm_kernel_time": (C.c_int, [_ctx, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "csm_reset_kernel_timing": (C.c_int, [_ctx]),

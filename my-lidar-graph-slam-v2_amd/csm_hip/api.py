@@ -219,6 +219,35 @@ class Context:
                                                    _ptr(init), C.byref(p), C.byref(out)))
         return summary_to_dict(out)
 
+    def _flatten_queries(self, queries):
+        n = len(queries)
+        arr = (L.LoopQuery * n)()
+        keep = []
+        for i, q in enumerate(queries):
+            a, r = _f64(q["angles"]), _f64(q["ranges"])
+            keep.append((a, r))
+            arr[i].map_id = q["map_id"]
+            arr[i].geometry = L.Geometry(*q["geom"])
+            arr[i].scan.angles = a.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].scan.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].scan.n_points = a.size
+            arr[i].scan.relative_sensor_pose[:] = list(q["rel_pose"])
+            arr[i].initial_pose[:] = list(q["init_pose"])
+        return arr, keep
+
+    def correlative_match_batch(self, queries, range_x, range_y, range_theta, low_resolution,
+                                score_threshold, known_rate_threshold):
+        """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose)."""
+        n = len(queries)
+        arr, keep = self._flatten_queries(queries)
+        p = L.CorrelativeParams()
+        p.range_x, p.range_y, p.range_theta = range_x, range_y, range_theta
+        p.low_resolution = low_resolution
+        p.score_threshold, p.known_rate_threshold = score_threshold, known_rate_threshold
+        out = (L.Summary * n)()
+        self._check(self.lib.csm_correlative_match_batch(self._ctx, arr, n, C.byref(p), out))
+        return [summary_to_dict(o) for o in out]
+
     def bnb_match_batch(self, queries, range_x, range_y, range_theta, node_height_max,
                         score_threshold, known_rate_threshold):
         """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose)."""

@@ -125,7 +125,7 @@ class LoopDetectorCorrelativeHIP:
     """Search part of LoopDetectorCorrelative::Detect
     (src/my_lidar_graph_slam/mapping/loop_detector_correlative.cpp:59-156): the
     correlative matcher with a coarse map cached per local-map id and the
-    detector's two thresholds, one query after the other."""
+    detector's two thresholds."""
 
     def __init__(self, name, ctx, low_resolution, range_x, range_y, range_theta,
                  score_threshold, known_rate_threshold):
@@ -137,13 +137,12 @@ class LoopDetectorCorrelativeHIP:
         self.known_rate_threshold = known_rate_threshold
 
     def detect(self, queries, grids=None):
-        """Returns (summaries in query order, indices of the found ones)."""
-        outs = []
+        """Returns (summaries in query order, indices of the found ones). All
+        queries go to the device in one batch (csm_correlative_match_batch)."""
         for q in queries:
             if not self.ctx.has_grid(q["map_id"]):
                 self.ctx.upload_grid(q["map_id"], grids[q["map_id"]])
-            outs.append(self.ctx.correlative_match(
-                q["map_id"], q["geom"], q["angles"], q["ranges"], q["rel_pose"], q["init_pose"],
-                self.ranges[0], self.ranges[1], self.ranges[2], self.low_resolution,
-                self.score_threshold, self.known_rate_threshold))
+        outs = self.ctx.correlative_match_batch(
+            queries, self.ranges[0], self.ranges[1], self.ranges[2], self.low_resolution,
+            self.score_threshold, self.known_rate_threshold) if queries else []
         return outs, [i for i, o in enumerate(outs) if o["pose_found"]]

@@ -1339,7 +1339,7 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
 
 namespace {
 
-struct BnbPrep {
+struct BatchPrep {
     DeviceGrid* grid = nullptr;
     int level[kMaxElig] = { 0 };   /* index into grid->levels of box-max(2^h) */
     int n_theta = 0, n = 0;
@@ -1365,7 +1365,7 @@ struct HeapNode {
  * discipline (std::priority_queue, same push / pop order as
  * src/mapping/scan_matcher_branch_bound.cpp:156-231) reading those scores
  * instead of calling Score(). No score is computed on the CPU. */
-int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BnbPrep& p, const csm_summary& o,
+int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BatchPrep& p, const csm_summary& o,
                 const csm_bnb_params* prm, csm_result* res)
 {
     const int H = prm->node_height_max;
@@ -1478,14 +1478,27 @@ int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BnbPrep& p, const c
     return CSM_OK;
 }
 
+/* What distinguishes the two batched searches. */
+struct BatchSpec {
+    bool bnb = true;          /* branch and bound (leaf + 2^h levels) or correlative (fine + one
+                                 box-max(L) level) */
+    int H = 0;                /* number of coarser levels */
+    int stride[kMaxElig] = { 1 };   /* stride[j] of level j (stride[0] = 1) */
+    int unit = 1;             /* candidate domain is padded to a multiple of this */
+    double range_x = 0, range_y = 0, range_theta = 0;
+    double score_thr = 0, known_thr = 0;
+    const csm_bnb_params* bnb_params = nullptr;
+    const csm_correlative_params* csm_params = nullptr;
+};
+
 /* One group of queries that share (nx, ny): the whole device pipeline. */
-int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector<int>& idx,
-                  const std::vector<std::vector<int>>& levels, const csm_bnb_params* prm,
-                  csm_summary* out)
+int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector<int>& idx,
+                    const std::vector<std::vector<int>>& levels, const BatchSpec& spec,
+                    csm_summary* out)
 {
-    const int H = prm->node_height_max;
+    const int H = spec.H;
     const int nq = (int)idx.size();
-    std::vector<BnbPrep> pp(nq);
+    std::vector<BatchPrep> pp(nq);
     int rc;
 
     /* ---- host set-up: window, projection products (threaded over queries) ---- */
@@ -1495,19 +1508,19 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     for (int k = 0; k < nq; ++k) {
         const csm_loop_query& q = queries[idx[k]];
         csm_summary& o = out[idx[k]];
-        BnbPrep& p = pp[k];
+        BatchPrep& p = pp[k];
         p.grid = find_grid(ctx, q.map_id);
         for (int h = 0; h <= H; ++h)
             p.level[h] = levels[idx[k]][h];
         csm_host_compound(q.initial_pose, q.scan.relative_sensor_pose, o.sensor_pose);
         csm_host_search_step(q.geometry.resolution, q.scan.ranges, q.scan.n_points, &o.step_x,
                              &o.step_y, &o.step_theta);
-        o.win_x = p.win_x = csm_host_window(prm->range_x, o.step_x);
-        o.win_y = p.win_y = csm_host_window(prm->range_y, o.step_y);
-        o.win_theta = p.win_t = csm_host_window(prm->range_theta, o.step_theta);
+        o.win_x = p.win_x = csm_host_window(spec.range_x, o.step_x);
+        o.win_y = p.win_y = csm_host_window(spec.range_y, o.step_y);
+        o.win_theta = p.win_t = csm_host_window(spec.range_theta, o.step_theta);
         p.n_theta = 2 * p.win_t + 1;
         p.n = q.scan.n_points;
-        const int big = 1 << H;
+        const int big = spec.unit;
         p.nx = ceil_div(2 * p.win_x + 1, big) * big;
         p.ny = ceil_div(2 * p.win_y + 1, big) * big;
         p.tiles_x = ceil_div(p.grid->cols + p.win_x + (-p.win_x + p.nx - 1), kTile);
@@ -1545,18 +1558,19 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     /* ---- launch geometry shared by the group ---- */
     std::vector<PassPlan> lp(H + 1);
     for (int h = 0; h <= H; ++h)
-        if (!plan_pass(nx >> h, ny >> h, 1 << h, &lp[h]))
-            return fail(ctx, CSM_EINVAL, "internal: no launch geometry for level %d", h);
+        if (!plan_pass(nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
+            return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
+                        spec.stride[h]);
     const int lstride = lp[0].lstride;
     const int ncb = lp[0].ncb();
 
     /* ---- workspaces ---- */
     size_t lvl_total = 0, best_total = 0;
     for (int k = 0; k < nq; ++k) {
-        BnbPrep& p = pp[k];
+        BatchPrep& p = pp[k];
         for (int h = 1; h <= H; ++h) {
             p.lvl_off[h] = lvl_total;
-            lvl_total += (size_t)p.n_theta * (nx >> h) * (ny >> h);
+            lvl_total += (size_t)p.n_theta * (nx / spec.stride[h]) * (ny / spec.stride[h]);
         }
         p.best_off = best_total;
         best_total += (size_t)p.n_theta * ncb;
@@ -1600,10 +1614,10 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     for (int k = 0; k < nq; ++k) {
         const csm_loop_query& q = queries[idx[k]];
         const csm_summary& o = out[idx[k]];
-        const BnbPrep& p = pp[k];
+        const BatchPrep& p = pp[k];
         const DeviceGrid& g = *p.grid;
         const int x_lo = -p.win_x, y_lo = -p.win_y;
-        const int min_known = csm_host_min_known(p.n, prm->known_rate_threshold);
+        const int min_known = csm_host_min_known(p.n, spec.known_thr);
 
         ProjJob& I = ij[k];
         std::memset(&I, 0, sizeof(I));
@@ -1622,7 +1636,8 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         I.off_x = q.geometry.offset_x;
         I.off_y = q.geometry.offset_y;
         I.res = q.geometry.resolution;
-        I.check_nodes = 1;
+        I.check_nodes = spec.bnb ? 1 : 0;
+        I.flag_uncertain = 1;
         I.x_lo = x_lo;
         I.y_lo = y_lo;
         I.nx = nx;
@@ -1655,9 +1670,9 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         B.lstride = lstride;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {
-            B.band_win[h - 1] = 1 << h;
-            B.band_nx[h - 1] = nx >> h;
-            B.band_ny[h - 1] = ny >> h;
+            B.band_win[h - 1] = spec.stride[h];
+            B.band_nx[h - 1] = nx / spec.stride[h];
+            B.band_ny[h - 1] = ny / spec.stride[h];
         }
 
         ScoreJob base;
@@ -1675,19 +1690,19 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         base.y_lo = y_lo;
         base.flags = d_flags + k;
         base.min_known = min_known;
-        base.rank_l = 1;
+        base.rank_l = spec.bnb ? 1 : spec.unit;
         for (int h = 1; h <= H; ++h) {
             ScoreJob& S = sj[h][k];
             S = base;
             S.cells = g.levels[p.level[h]].cells;
-            S.nx = nx >> h;
-            S.ny = ny >> h;
-            S.stride = 1 << h;
-            S.log2_stride = h;
+            S.nx = nx / spec.stride[h];
+            S.ny = ny / spec.stride[h];
+            S.stride = spec.stride[h];
+            S.log2_stride = ilog2_exact(spec.stride[h]);
             /* a leaf's own known count bounds every ancestor's from below when
              * no read can fall in the edge band: the level passes are only
              * needed to detect (and then handle) that case */
-            S.skip_unless_band = 1;
+            S.skip_unless_band = spec.bnb ? 1 : (min_known <= 1);
             S.sorted_pb = B.sorted_rc;
             S.acc_s = d_lvl_s + p.lvl_off[h];
             S.acc_k = d_lvl_k + p.lvl_off[h];
@@ -1699,15 +1714,17 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         F.ny = ny;
         F.stride = 1;
         F.block_best = d_best + p.best_off;
-        F.check_own_known = 1;
-        F.elig_only_if_band = 1;
+        /* branch and bound tests every popped node, leaf included; the
+         * correlative sweep tests the coarse node only */
+        F.check_own_known = spec.bnb || H == 0;
+        F.elig_only_if_band = spec.bnb ? 1 : (min_known <= 1);
         F.n_elig = H;
         for (int h = 1; h <= H; ++h) {
             F.elig[h - 1].k = d_lvl_k + p.lvl_off[h];
             F.elig[h - 1].s = d_lvl_s + p.lvl_off[h];
-            F.elig[h - 1].div = 1 << h;
-            F.elig[h - 1].nxc = nx >> h;
-            F.elig[h - 1].nyc = ny >> h;
+            F.elig[h - 1].div = spec.stride[h];
+            F.elig[h - 1].nxc = nx / spec.stride[h];
+            F.elig[h - 1].nyc = ny / spec.stride[h];
         }
 
         FinalJob& Z = fj[k];
@@ -1716,13 +1733,14 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         Z.n_entries = p.n_theta * ncb;
         Z.nx = nx;
         Z.ny = ny;
-        Z.rank_l = 1;
+        Z.rank_l = spec.bnb ? 1 : spec.unit;
         Z.x_lo = x_lo;
         Z.y_lo = y_lo;
         Z.win_theta = p.win_t;
-        Z.init_x = 0;     /* scan_matcher_branch_bound.cpp:144-146 */
-        Z.init_y = 0;
-        Z.init_theta = 0;
+        /* scan_matcher_branch_bound.cpp:144-146 / scan_matcher_correlative.cpp:149-152 */
+        Z.init_x = spec.bnb ? 0 : -p.win_x;
+        Z.init_y = spec.bnb ? 0 : -p.win_y;
+        Z.init_theta = spec.bnb ? 0 : -p.win_t;
         Z.cells = F.cells;
         Z.rows = g.rows;
         Z.cols = g.cols;
@@ -1730,7 +1748,7 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
         Z.hit_col = I.hit_col;
         Z.hit_row = I.hit_row;
         Z.n_points = p.n;
-        Z.score_thr = prm->score_threshold;
+        Z.score_thr = spec.score_thr;
         Z.lut = ctx->lut_dev;
         Z.flags_in = d_flags + k;
         Z.out = d_out + k;
@@ -1800,9 +1818,22 @@ int run_bnb_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector
     for (int k = 0; k < nq; ++k) {
         const csm_loop_query& q = queries[idx[k]];
         csm_summary& o = out[idx[k]];
-        if (res[k].flags & (CSM_FLAG_EDGE_BAND | CSM_FLAG_KEY_TIE | CSM_FLAG_PROJ_DELTA))
-            if ((rc = bnb_literal(ctx, q, pp[k], o, prm, &res[k])))
-                return rc;
+        if (res[k].flags & (CSM_FLAG_EDGE_BAND | CSM_FLAG_KEY_TIE | CSM_FLAG_PROJ_DELTA)) {
+            if (spec.bnb) {
+                if ((rc = bnb_literal(ctx, q, pp[k], o, spec.bnb_params, &res[k])))
+                    return rc;
+            } else {
+                /* exact single-query path (host-verified projection, tie replay,
+                 * literal sweep) */
+                const uint32_t why = res[k].flags;
+                csm_summary one;
+                if ((rc = csm_correlative_match(ctx, q.map_id, &q.geometry, &q.scan, q.initial_pose,
+                                                spec.csm_params, &one)))
+                    return rc;
+                res[k] = one.raw;
+                res[k].flags |= why & CSM_FLAG_PROJ_DELTA;
+            }
+        }
         o.raw = res[k];
         o.pose_found = o.raw.found;
         /* scan_matcher_branch_bound.cpp:238-247 */
@@ -1860,7 +1891,19 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
         groups[{ nx, ny }].push_back(i);
     }
     for (auto& kv : groups) {
-        int rc = run_bnb_group(ctx, queries, kv.second, levels, prm, out);
+        BatchSpec spec;
+        spec.bnb = true;
+        spec.H = H;
+        for (int h = 0; h <= H; ++h)
+            spec.stride[h] = 1 << h;
+        spec.unit = 1 << H;
+        spec.range_x = prm->range_x;
+        spec.range_y = prm->range_y;
+        spec.range_theta = prm->range_theta;
+        spec.score_thr = prm->score_threshold;
+        spec.known_thr = prm->known_rate_threshold;
+        spec.bnb_params = prm;
+        int rc = run_batch_group(ctx, queries, kv.second, levels, spec, out);
         if (rc)
             return rc;
     }
@@ -1870,6 +1913,69 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
     for (int i = 0; i < n_queries; ++i) {
         out[i].input_setup_us = setup / n_queries;
         out[i].optimization_us = opt / n_queries;
+    }
+    return CSM_OK;
+}
+
+/* LoopDetectorCorrelative::Detect's search part for a batch of queries
+ * (src/mapping/loop_detector_correlative.cpp:59-156 lines 68-108): one coarse
+ * map per local map id, cached on the device like mPrecompMaps. */
+int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_queries,
+                                const csm_correlative_params* prm, csm_summary* out)
+{
+    if (!ctx || !queries || n_queries < 1 || !prm || !out || prm->low_resolution < 1)
+        return fail(ctx, CSM_EINVAL, "csm_correlative_match_batch: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int L = prm->low_resolution;
+    const int H = L > 1 ? 1 : 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
+    for (int i = 0; i < n_queries; ++i) {
+        if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
+            return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
+        DeviceGrid* g = find_grid(ctx, queries[i].map_id);
+        if (!g)
+            return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
+                        (unsigned long long)queries[i].map_id);
+        if (H) {
+            int rc = level_for_window(ctx, *g, L, &levels[i][1]);
+            if (rc)
+                return rc;
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    std::memset(out, 0, sizeof(csm_summary) * (size_t)n_queries);
+    std::map<std::pair<int, int>, std::vector<int>> groups;
+    for (int i = 0; i < n_queries; ++i) {
+        double sx, sy, st;
+        csm_host_search_step(queries[i].geometry.resolution, queries[i].scan.ranges,
+                             queries[i].scan.n_points, &sx, &sy, &st);
+        const int nx = ceil_div(2 * csm_host_window(prm->range_x, sx) + 1, L) * L;
+        const int ny = ceil_div(2 * csm_host_window(prm->range_y, sy) + 1, L) * L;
+        groups[{ nx, ny }].push_back(i);
+    }
+    for (auto& kv : groups) {
+        BatchSpec spec;
+        spec.bnb = false;
+        spec.H = H;
+        spec.stride[0] = 1;
+        spec.stride[1] = L;
+        spec.unit = L;
+        spec.range_x = prm->range_x;
+        spec.range_y = prm->range_y;
+        spec.range_theta = prm->range_theta;
+        spec.score_thr = prm->score_threshold;
+        spec.known_thr = prm->known_rate_threshold;
+        spec.csm_params = prm;
+        int rc = run_batch_group(ctx, queries, kv.second, levels, spec, out);
+        if (rc)
+            return rc;
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n_queries; ++i) {
+        out[i].input_setup_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / n_queries;
+        out[i].optimization_us = std::chrono::duration<double, std::micro>(t2 - t1).count() / n_queries;
     }
     return CSM_OK;
 }

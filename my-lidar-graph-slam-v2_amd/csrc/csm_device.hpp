@@ -151,6 +151,7 @@ struct ProjJob {
     /* branch and bound: also certify every per-node projection
      * floor((sensor + x*step + r*cos - off) / res) == base + x */
     int32_t check_nodes;
+    int32_t flag_uncertain;    /* set CSM_FLAG_PROJ_DELTA in *flags instead of listing */
     int32_t x_lo, y_lo, nx, ny;
     double step_x, step_y;
     uint32_t* flags;           /* CSM_FLAG_PROJ_DELTA when a node cannot be certified */

@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void proj_body(const ProjJob& job)
         }
     }
     if (uncertain) {
-        if (job.check_nodes) {
+        if (job.check_nodes || job.flag_uncertain) {
             atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
         } else {
             const uint32_t pos = atomicAdd(job.unc_count, 1u);

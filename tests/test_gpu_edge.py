@@ -133,3 +133,34 @@ def test_zz_edge_paths_were_exercised():
     print("edge-path statistics:", stats)
     assert stats["tie"] > 0
     assert stats["literal"] > 0
+
+
+def test_correlative_batch_mixes_fast_and_exact_paths(gpu_ctx, oracle):
+    """csm_correlative_match_batch: ordinary, tie-prone, edge-band and
+    cell-edge-aligned queries in ONE batch; each must equal the literal sweep."""
+    cases = [
+        synth.csm_case(120, n_beams=540),
+        synth.csm_case(121, n_beams=540, levels=3, interior_unknown=0.0),
+        synth.csm_case(122, n_beams=540, rows=256, cols=288, origin="low_edge", half_x=5.2,
+                       half_y=4.4, init_error=(0.23, 0.19, 0.03)),
+        synth.csm_case(123, n_beams=540, origin="aligned", truth=(0.0, 0.0, 0.0),
+                       init_error=(0.25, -0.15, 0.0)),
+        synth.csm_case(124, n_beams=540),
+    ]
+    for Lr, thr in ((4, (0.0, 0.0)), (5, (0.3, 0.5)), (1, (0.2, 0.3))):
+        qs = []
+        for i, c in enumerate(cases):
+            gpu_ctx.upload_grid(8000 + i, c["grid"])
+            qs.append(dict(map_id=8000 + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+                           rel_pose=c["rel_pose"], init_pose=c["init_pose"]))
+        outs = gpu_ctx.correlative_match_batch(qs, 1.0, 1.0, math.radians(10), Lr, thr[0], thr[1])
+        for c, o in zip(cases, outs):
+            lit = oracle.csm(c, 1.0, 1.0, math.radians(10), Lr, thr[0], thr[1])
+            raw = o["raw"]
+            assert o["pose_found"] == lit["found"], (Lr, raw, lit)
+            assert (raw["best_x"], raw["best_y"], raw["best_theta"]) == \
+                (lit["bestX"], lit["bestY"], lit["bestT"]), (Lr, raw, lit)
+            assert raw["score"] == lit["scoreMax"]
+            assert o["estimated_pose"] == lit["estimatedPose"]
+        for i in range(len(cases)):
+            gpu_ctx.release_grid(8000 + i)
