@@ -44,6 +44,23 @@ def main():
                                             poses_per_s=r["candidates"] / dt,
                                             found=r["pose_found"])
 
+    # config 2, batched: the same window for 8 / 64 scans in one call
+    rng2 = np.random.RandomState(11)
+    for nb in (8, 64):
+        qs = []
+        for i in range(nb):
+            init = tuple(np.asarray(case["truth"]) + rng2.uniform(-0.3, 0.3, 3) * (1, 1, 0.2))
+            qs.append(dict(map_id=1, geom=case["geom"], angles=case["angles"], ranges=case["ranges"],
+                           rel_pose=case["rel_pose"], init_pose=init))
+        ctx.correlative_match_batch(qs, 4.0, 4.0, math.radians(60), 4, 0.0, 0.0)
+        t0 = time.perf_counter()
+        outs = ctx.correlative_match_batch(qs, 4.0, 4.0, math.radians(60), 4, 0.0, 0.0)
+        dt = time.perf_counter() - t0
+        cands = sum(o["candidates"] for o in outs)
+        out["config2_batch_%d" % nb] = dict(ms_per_batch=dt * 1e3, poses_per_s=cands / dt,
+                                            found=sum(o["pose_found"] for o in outs),
+                                            flagged=sum(1 for o in outs if o["raw"]["flags"]))
+
     # config 3: one scan against n_sub submaps
     base = synth.csm_case(1000, n_beams=1080, fov=1.5 * math.pi)
     rng = np.random.RandomState(3)
