@@ -52,6 +52,20 @@ def make_workload(rank, n_scans):
     return dict(grid=grid, geom=geom, scans=scans, params=(rx, ry, rt, L))
 
 
+def pmc_traffic():
+    """HBM bytes per fine-kernel launch from the committed PMC passes
+    (profiles/r01_pmc_fine_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate runs of this same bench, FETCH_SIZE doubled per the gfx950
+    note). A live bench run cannot collect counters itself; null when the file
+    is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fine_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(wl, budget_s=12.0, max_scans=400):
     """The CPU oracle (literal ScanMatcherCorrelative sweep with pruning), one
     core, on the first scans of the same workload."""
@@ -256,7 +270,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(),
                 "avg_launch_us": avg_fine_s * 1e6,
                 "launches": fine_n,
                 "algorithmic_bytes_per_launch": alg_bytes,
