@@ -167,6 +167,22 @@ double value_to_probability(unsigned v)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+/* k_bin's LDS: 6 per-tile arrays, 2 * kBlock scan words, hash keys + values */
+int n_points_max_for_hash(int n) { return n; }
+
+int bin_hash_size(int n_points)
+{
+    int h = 1024;
+    while (h < 2 * n_points && h < 16384)
+        h <<= 1;
+    return h;
+}
+
+size_t bin_lds_bytes(int tiles, int n_points)
+{
+    return ((size_t)6 * tiles + 2 * kBlock + 2 * (size_t)bin_hash_size(n_points)) * 4;
+}
+
 
 
 
@@ -314,8 +330,10 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
     p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi, kTile);
     p->max_tiles = std::min(p->n, p->tiles_x * p->tiles_y) + p->n / kPbMax + 1;
-    const size_t bin_lds = (6 * (size_t)p->tiles_x * p->tiles_y + 2 * kBlock) * 4;
-    if (bin_lds > 160 * 1024)
+    if (p->n > kMaxPoints)
+        return fail(ctx, CSM_EINVAL, "more than %d beams per scan", kMaxPoints);
+    const size_t bin_lds = bin_lds_bytes(p->tiles_x * p->tiles_y, p->n);
+    if (bin_lds > 160 * 1024 - 64)
         return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
     return CSM_OK;
 }
@@ -490,7 +508,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     const size_t nt = p.n_theta;
     if ((rc = ensure(ctx, ctx->sorted, nt * p.n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->tiles, nt * p.max_tiles * sizeof(TileRec)))) return rc;
-    if ((rc = ensure(ctx, ctx->ntiles, nt * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ntiles, nt * 8))) return rc;
     if ((rc = ensure(ctx, ctx->misc, 256))) return rc;
     if ((rc = ensure(ctx, ctx->coarse_s, nt * p.nxc * p.nyc * 4))) return rc;
     if ((rc = ensure(ctx, ctx->coarse_k, nt * p.nxc * p.nyc * 4))) return rc;
@@ -528,6 +546,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.tiles_y = p.tiles_y;
     bj.known_r0 = g.known_r0;
     bj.known_c0 = g.known_c0;
+    bj.hash_size = bin_hash_size(p.n);
     bj.lstride = p.fine.lstride;
     bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
     if (p.L > 1) {
@@ -541,7 +560,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         bj.zero_words = p.nxc * p.nyc;
     }
     {
-        const size_t lds = (6 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4;
+        const size_t lds = bin_lds_bytes(p.tiles_x * p.tiles_y, p.n);
         if ((rc = set_lds(ctx, k_bin, lds))) return rc;
         ScopedTimer tm(ctx, "bin");
         hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBlock), lds, ctx->stream, bj);
@@ -1526,17 +1545,19 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         p.tiles_x = ceil_div(p.grid->cols + p.win_x + (-p.win_x + p.nx - 1), kTile);
         p.tiles_y = ceil_div(p.grid->rows + p.win_y + (-p.win_y + p.ny - 1), kTile);
         p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y) + p.n / kPbMax + 1;
-        bin_lds = std::max(bin_lds, (6 * (size_t)p.tiles_x * p.tiles_y + 2 * kBlock) * 4);
+        if (p.n > kMaxPoints)
+            return fail(ctx, CSM_EINVAL, "query %d: more than %d beams per scan", idx[k], kMaxPoints);
+        bin_lds = std::max(bin_lds, bin_lds_bytes(p.tiles_x * p.tiles_y, n_points_max_for_hash(p.n)));
         p.hit_off = hit_total;
         p.tile_off = tile_total;
         p.theta_off = theta_total;
         hit_total += (size_t)p.n_theta * p.n;
         tile_total += (size_t)p.n_theta * p.max_tiles;
-        theta_total += p.n_theta;
+        theta_total += 2 * (size_t)p.n_theta;     /* record counts + merge flags */
         n_theta_max = std::max(n_theta_max, p.n_theta);
         n_points_max = std::max(n_points_max, p.n);
     }
-    if (bin_lds > 160 * 1024)
+    if (bin_lds > 160 * 1024 - 64)
         return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
     const int nx = pp[0].nx, ny = pp[0].ny;
 
@@ -1667,6 +1688,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.tiles_y = p.tiles_y;
         B.known_r0 = g.known_r0;
         B.known_c0 = g.known_c0;
+        B.hash_size = bin_hash_size(p.n);
         B.lstride = lstride;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {

@@ -10,7 +10,9 @@ namespace csm {
 constexpr int kTile = 64;        /* endpoint tile edge, cells */
 constexpr int kMaxRegionRows = 128;        /* LDS region rows of a stride-1 job */
 constexpr int kMaxRegionRowsStrided = 128; /* ... of a strided (coarser level) job */
-constexpr int kPbMax = 1024;       /* beams per TileRec: k_bin splits fuller tiles */
+constexpr int kPbMax = 1024;       /* entries per TileRec: k_bin splits fuller tiles */
+constexpr int kMaxMult = 15;       /* beams merged into one (cell, multiplicity) entry */
+constexpr int kMaxPoints = 12288;  /* beams per scan (hash table of k_bin: 16384 slots) */
 constexpr int kBlock = 512;      /* threads per workgroup (8 wave64) */
 constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
 /* internal flag bit (never returned): some beam can reach the negative edge
@@ -61,6 +63,7 @@ struct BinJob {
     int32_t x_lo, y_lo;        /* most negative candidate offset */
     int32_t x_hi, y_hi;        /* most positive candidate offset */
     int32_t tiles_x, tiles_y;
+    int32_t hash_size;         /* power of two >= 4/3 n_points (LDS hash table of k_bin) */
     int32_t lstride;
     /* first row / column of the map that holds a known cell: a box that ends
      * before it is unknown on every level, so reading it as unknown is right */

@@ -65,13 +65,15 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
     extern __shared__ uint32_t sm_bin[];
     const int ntile = job.tiles_x * job.tiles_y;
-    uint32_t* hist = sm_bin;            /* [ntile] counts, later cursors */
+    uint32_t* hist = sm_bin;            /* [ntile] entry counts, later cursors */
     uint32_t* first = sm_bin + ntile;   /* [ntile] start offsets */
     uint32_t* bb_rmin = first + ntile;  /* [ntile] beam bounding box inside the tile */
     uint32_t* bb_rmax = bb_rmin + ntile;
     uint32_t* bb_cmin = bb_rmax + ntile;
     uint32_t* bb_cmax = bb_cmin + ntile;
     uint32_t* part = bb_cmax + ntile;   /* [2 * kBlock] */
+    uint32_t* hkey = part + 2 * kBlock; /* [hash_size] (tile, cell) + 1, 0 = empty */
+    uint32_t* hval = hkey + job.hash_size;   /* [hash_size] beams on that cell */
     const int t = blockIdx.x;
     if (t >= job.n_theta)
         return;
@@ -79,6 +81,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int n = job.n_points;
     const int32_t* col = job.hit_col + (size_t)t * n;
     const int32_t* row = job.hit_row + (size_t)t * n;
+    const uint32_t hmask = (uint32_t)job.hash_size - 1u;
 
     if (job.zero_a)
         for (int i = tid; i < job.zero_words; i += kBlock) {
@@ -92,8 +95,15 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         bb_rmax[i] = 0;
         bb_cmax[i] = 0;
     }
+    for (int i = tid; i < job.hash_size; i += kBlock) {
+        hkey[i] = 0;
+        hval[i] = 0;
+    }
     __syncthreads();
 
+    /* Pass A: beams that land on the same cell of this slice contribute the
+     * same value to every candidate, so they are merged: a small LDS hash
+     * table counts the beams per (tile, cell). */
     const int r_max = job.rows - 1 - job.y_lo;
     const int c_max = job.cols - 1 - job.x_lo;
     bool band = false;
@@ -102,11 +112,21 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         const int rr = r + job.y_hi, cc = c + job.x_hi;
         if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
             const int tile = (rr / kTile) * job.tiles_x + cc / kTile;
-            atomicAdd(&hist[tile], 1u);
-            atomicMin(&bb_rmin[tile], (uint32_t)(rr % kTile));
-            atomicMax(&bb_rmax[tile], (uint32_t)(rr % kTile));
-            atomicMin(&bb_cmin[tile], (uint32_t)(cc % kTile));
-            atomicMax(&bb_cmax[tile], (uint32_t)(cc % kTile));
+            const uint32_t rb = (uint32_t)(rr % kTile), cb = (uint32_t)(cc % kTile);
+            atomicMin(&bb_rmin[tile], rb);
+            atomicMax(&bb_rmax[tile], rb);
+            atomicMin(&bb_cmin[tile], cb);
+            atomicMax(&bb_cmax[tile], cb);
+            const uint32_t key = (((uint32_t)tile << 12) | (rb << 6) | cb) + 1u;
+            uint32_t slot = (key * 2654435761u) >> 12 & hmask;
+            while (true) {
+                const uint32_t old = atomicCAS(&hkey[slot], 0u, key);
+                if (old == 0u || old == key) {
+                    atomicAdd(&hval[slot], 1u);
+                    break;
+                }
+                slot = (slot + 1u) & hmask;
+            }
         }
         for (int b = 0; b < job.n_band; ++b) {
             const int w = job.band_win[b];
@@ -119,7 +139,17 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         atomicOr(job.flags, kFlagBandTouch);
     __syncthreads();
 
-    /* exclusive scan of counts and of the non-empty flags */
+    constexpr uint32_t max_mult = kMaxMult;
+
+    /* Pass B: entries per tile (a cell with more than max_mult beams is split) */
+    for (int sl = tid; sl < job.hash_size; sl += kBlock) {
+        const uint32_t key = hkey[sl];
+        if (key)
+            atomicAdd(&hist[(key - 1u) >> 12], (hval[sl] + max_mult - 1) / max_mult);
+    }
+    __syncthreads();
+
+    /* exclusive scan of entry counts and of the records per tile */
     const int chunk = (ntile + kBlock - 1) / kBlock;
     const int lo = tid * chunk, hi = min(lo + chunk, ntile);
     uint32_t cnt = 0, ne = 0;
@@ -127,12 +157,8 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         cnt += hist[i];
         ne += (hist[i] + kPbMax - 1) / kPbMax;
     }
-    part[tid] = cnt;
-    part[kBlock + tid] = ne;
-    __syncthreads();
     {
-        /* exclusive scan over the kBlock partials: wave64 shuffles, then the
-         * four wave totals */
+        /* wave64 shuffles, then the wave totals */
         uint32_t a = cnt, b = ne;
         const int ln = tid & 63;
 #pragma unroll
@@ -160,7 +186,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             job.n_tiles[t] = (int32_t)(bb2 + b);
     }
     __syncthreads();
-    uint32_t off = part[tid], slot = part[kBlock + tid];
+    uint32_t off = part[tid], slot_rec = part[kBlock + tid];
     TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     for (int i = lo; i < hi; ++i) {
         const uint32_t c = hist[i];
@@ -174,7 +200,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             rec.h = (int)(bb_rmax[i] - bb_rmin[i]) + 1;
             rec.w = (int)(bb_cmax[i] - bb_cmin[i]) + 1;
             rec.pad[0] = rec.pad[1] = 0;
-            recs[slot++] = rec;
+            recs[slot_rec++] = rec;
         }
         off += c;
     }
@@ -183,19 +209,29 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         hist[i] = first[i];
     __syncthreads();
 
+    /* Pass C: one entry per (cell, <= kMaxMult beams): offset inside the
+     * tile's bounding box + multiplicity.
+     *   sorted_pb: mult << 16 | (row * lstride + col)       (stride-1 jobs)
+     *   sorted_rc: mult << 24 | row << 16 | col             (strided jobs)  */
     uint32_t* out = job.sorted_pb + (size_t)t * n;
-    for (int i = tid; i < n; i += kBlock) {
-        const int r = row[i], c = col[i];
-        const int rr = r + job.y_hi, cc = c + job.x_hi;
-        if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
-            const int ty = rr / kTile, tx = cc / kTile;
-            const int tile = ty * job.tiles_x + tx;
-            const uint32_t pos = atomicAdd(&hist[tile], 1u);
-            const int rb = rr - ty * kTile - (int)bb_rmin[tile];
-            const int cb = cc - tx * kTile - (int)bb_cmin[tile];
-            out[pos] = (uint32_t)(rb * job.lstride + cb);
-            if (job.sorted_rc)
-                job.sorted_rc[(size_t)t * n + pos] = ((uint32_t)rb << 16) | (uint32_t)cb;
+    uint32_t* out_rc = job.sorted_rc ? job.sorted_rc + (size_t)t * n : nullptr;
+    for (int sl = tid; sl < job.hash_size; sl += kBlock) {
+        const uint32_t key = hkey[sl];
+        if (!key)
+            continue;
+        const uint32_t k1 = key - 1u;
+        const int tile = (int)(k1 >> 12);
+        const uint32_t rb = ((k1 >> 6) & 63u) - bb_rmin[tile];
+        const uint32_t cb = (k1 & 63u) - bb_cmin[tile];
+        uint32_t beams = hval[sl];
+        const uint32_t entries = (beams + max_mult - 1) / max_mult;
+        uint32_t pos = atomicAdd(&hist[tile], entries);
+        for (; beams > 0; ++pos) {
+            const uint32_t m = min(beams, max_mult);
+            beams -= m;
+            out[pos] = (m << 16) | (rb * (uint32_t)job.lstride + cb);
+            if (out_rc)
+                out_rc[pos] = (m << 24) | (rb << 16) | cb;
         }
     }
 }
@@ -285,8 +321,8 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     const int tb = lane_on ? (g * R) * LSTRIDE + dxi : 0;
     const int lane = tid & 63;
 
-    /* acc packs (known count << 24) + (sum of values) of at most 255 beams;
-     * S, K are the exact totals */
+    /* acc packs (known count << 23) + (sum of values) of at most 128 beams
+     * (counted with multiplicity); S, K are the exact totals */
     uint32_t S[R], K[R], acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -298,8 +334,8 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     auto flush = [&]() {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            S[r] += acc[r] & 0xffffffu;
-            K[r] += acc[r] >> 24;
+            S[r] += acc[r] & 0x7fffffu;
+            K[r] += acc[r] >> 23;
             acc[r] = 0;
         }
         pending = 0;
@@ -363,7 +399,8 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
             pre_pb[q] = bi < tr.count ? pbs[tr.start + bi] : 0u;
         }
     };
-    auto expand = [](uint32_t v) { return v + (min(v, 1u) << 24); };
+    /* 24 bits, so that v_mad_u32_u24 can weight a cell by its beam count */
+    auto expand = [](uint32_t v) { return v + (min(v, 1u) << 23); };
     int ti = slice;
     if (ti < ntiles) {
         rec = recs[ti];
@@ -441,39 +478,54 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
         const int a = (cur.c0 + x0) & 7;
         const int cnt = (int)cur.count;
         const uint32_t* base = sm_cells + tb + a;
-        auto gather = [&](uint32_t pbv) {
-            uint32_t off = pbv;
+        /* entry = cell offset + number of beams on that cell (<= kMaxMult) */
+        auto locate = [&](uint32_t pbv) -> const uint32_t* {
+            uint32_t off;
             if (STRIDED) {
-                /* pbv = (row << 16 | col) inside the bounding box */
-                const uint32_t rb = pbv >> 16, cbm = (pbv & 0xffffu) + (uint32_t)a;
+                /* pbv = mult << 24 | row << 16 | col inside the bounding box */
+                const uint32_t rb = (pbv >> 16) & 0xffu, cbm = (pbv & 0xffffu) + (uint32_t)a;
                 off = (smod(rb) * hd + sdiv(rb)) * LSTRIDE + smod(cbm) * wd + sdiv(cbm);
+            } else {
+                off = pbv & 0xffffu;
             }
-            const uint32_t* p = (STRIDED ? sm_cells + tb : base) + off;
+            return (STRIDED ? sm_cells + tb : base) + off;
+        };
+        auto gather = [&](uint32_t pbv) {          /* weighted by the beam count */
+            const uint32_t m = STRIDED ? pbv >> 24 : pbv >> 16;
+            const uint32_t* p = locate(pbv);
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                acc[r] += p[r * LSTRIDE];
+                acc[r] = __umul24(p[r * LSTRIDE], m) + acc[r];
         };
-        /* beam offsets: 64 per LDS read, broadcast with v_readlane */
+        auto mult_of = [&](uint32_t pbv) { return STRIDED ? pbv >> 24 : pbv >> 16; };
+        /* entries: 64 per LDS read, broadcast with v_readlane */
         uint32_t pb_cur = lpb[lane];
         for (int b0 = 0; b0 < cnt; b0 += 64) {
             const uint32_t pb_nxt = lpb[(b0 + 64 + lane) & (kPbMax - 1)];
             const int m = min(64, cnt - b0);
-            if (pending + m > 255)
-                flush();
-            pending += m;
             int j = 0;
             for (; j + 4 <= m; j += 4) {
                 const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j);
                 const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j + 1);
                 const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j + 2);
                 const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j + 3);
+                const int mm = (int)(mult_of(o0) + mult_of(o1) + mult_of(o2) + mult_of(o3));
+                if (pending + mm > 128)
+                    flush();
+                pending += mm;
                 gather(o0);
                 gather(o1);
                 gather(o2);
                 gather(o3);
             }
-            for (; j < m; ++j)
-                gather((uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j));
+            for (; j < m; ++j) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j);
+                const int mm = (int)mult_of(o);
+                if (pending + mm > 128)
+                    flush();
+                pending += mm;
+                gather(o);
+            }
             pb_cur = pb_nxt;
         }
     }
