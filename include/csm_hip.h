@@ -204,7 +204,9 @@ typedef struct {
     int32_t low_resolution;   /* L; level `coarse_level` must be box-max(L) */
     int32_t coarse_level;
     int32_t min_known;        /* csm_host_min_known() */
-    int32_t reserved;
+    int32_t merge_mode;       /* 0: merge beams that land on the same cell into
+                                 weighted entries (default); 1: one entry per beam
+                                 (better when beams rarely share cells) */
     double  score_threshold;
 } csm_window;
 

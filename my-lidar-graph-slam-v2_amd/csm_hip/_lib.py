@@ -83,7 +83,7 @@ class Window(C.Structure):
     _fields_ = [("n_theta", C.c_int32), ("n_points", C.c_int32),
                 ("win_x", C.c_int32), ("win_y", C.c_int32),
                 ("low_resolution", C.c_int32), ("coarse_level", C.c_int32),
-                ("min_known", C.c_int32), ("reserved", C.c_int32),
+                ("min_known", C.c_int32), ("merge_mode", C.c_int32),
                 ("score_threshold", C.c_double)]
 
 

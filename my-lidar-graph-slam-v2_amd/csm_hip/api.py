@@ -167,8 +167,9 @@ class Context:
 
     @staticmethod
     def make_window(n_theta, n_points, win_x, win_y, low_resolution, coarse_level,
-                    min_known, score_threshold):
+                    min_known, score_threshold, merge_mode=0):
         w = L.Window()
+        w.merge_mode = merge_mode
         w.n_theta, w.n_points = n_theta, n_points
         w.win_x, w.win_y = win_x, win_y
         w.low_resolution, w.coarse_level = low_resolution, coarse_level

@@ -167,6 +167,24 @@ double value_to_probability(unsigned v)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+/* Do enough beams share cells for merging to pay? A merged entry costs a
+ * multiply per gather (~3x the vector work of the plain path) and saves LDS
+ * reads in proportion to the duplicates: break-even near 1.4 beams per cell
+ * (measured: config 2, 1.9 beams per cell, 108 -> 93 us; config 5, 1.15, 91 ->
+ * 98 ms). Estimated from the scan alone: a beam of range r next to a neighbour
+ * d_theta away opens a new cell with probability ~ min(1, r * d_theta / res). */
+bool merging_pays(const double* angles, const double* ranges, int n, double res)
+{
+    if (n < 2)
+        return false;
+    double cells = 1.0;
+    for (int i = 1; i < n; ++i) {
+        const double arc = std::fabs(angles[i] - angles[i - 1]) * 0.5 * (ranges[i] + ranges[i - 1]);
+        cells += std::min(1.0, arc / res);
+    }
+    return n >= 1.4 * cells;
+}
+
 /* k_bin's LDS: 6 per-tile arrays, 2 * kBlock scan words, hash keys + values */
 int n_points_max_for_hash(int n) { return n; }
 
@@ -193,6 +211,7 @@ const int kCoarseSlices = 8;
 struct PassPlan {
     int nx = 0, ny = 0, stride = 1, log2s = 0;
     int cbx = 0, groups = 0, R = 0, ncbx = 0, ncby = 0, lstride = 0;
+    bool weighted = true;     /* entries carry beam multiplicities */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -325,6 +344,7 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     p->y_hi = p->y_lo + p->ny - 1;
     if (!plan_pass(p->nx, p->ny, 1, &p->fine))
         return fail(ctx, CSM_EINVAL, "internal: no launch geometry for the fine level");
+    p->fine.weighted = w->merge_mode == 0;
     if (p->L > 1 && !plan_pass(p->nxc, p->nyc, p->L, &p->coarse))
         return fail(ctx, CSM_EINVAL, "LowResolution %d too large for the coarse kernel", p->L);
     p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
@@ -352,7 +372,11 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
  * {4..8}; strided kernels for LSTRIDE in {128,192} x R in {1,2,4}. */
 #define SCORE_CASE(LS, RR, ST, CALL)                                                   \
     if (pp.lstride == LS && pp.R == RR && mode == ST) {                                \
-        CALL(LS, RR, ST);                                                              \
+        if (pp.weighted || ST != 0) {                                                  \
+            CALL(LS, RR, ST, true);                                                    \
+        } else {                                                                       \
+            CALL(LS, RR, ST, false);                                                   \
+        }                                                                              \
         launched = true;                                                               \
     }
 #define SCORE_DISPATCH(CALL)                                                           \
@@ -375,21 +399,21 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         SCORE_CASE(192, 2, 2, CALL) SCORE_CASE(192, 4, 2, CALL)                        \
     } while (0)
 
-#define CALL_SINGLE(LS, RR, ST)                                                        \
+#define CALL_SINGLE(LS, RR, ST, WW)                                                    \
     do {                                                                               \
-        int rc_ = set_lds(ctx, k_score<LS, RR, ST>, lds);                              \
+        int rc_ = set_lds(ctx, k_score<LS, RR, ST, WW>, lds);                          \
         if (rc_)                                                                       \
             return rc_;                                                                \
-        hipLaunchKernelGGL((k_score<LS, RR, ST>), grid, dim3(kBlock), lds, ctx->stream, \
+        hipLaunchKernelGGL((k_score<LS, RR, ST, WW>), grid, dim3(kBlock), lds, ctx->stream, \
                            job, pp.cbx, pp.groups, n_buf);                             \
     } while (0)
 
-#define CALL_BATCH(LS, RR, ST)                                                         \
+#define CALL_BATCH(LS, RR, ST, WW)                                                     \
     do {                                                                               \
-        int rc_ = set_lds(ctx, k_score_batch<LS, RR, ST>, lds);                        \
+        int rc_ = set_lds(ctx, k_score_batch<LS, RR, ST, WW>, lds);                    \
         if (rc_)                                                                       \
             return rc_;                                                                \
-        hipLaunchKernelGGL((k_score_batch<LS, RR, ST>), grid, dim3(kBlock), lds,       \
+        hipLaunchKernelGGL((k_score_batch<LS, RR, ST, WW>), grid, dim3(kBlock), lds,   \
                            ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices, n_buf); \
     } while (0)
 
@@ -547,6 +571,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.known_r0 = g.known_r0;
     bj.known_c0 = g.known_c0;
     bj.hash_size = bin_hash_size(p.n);
+    bj.max_mult = p.fine.weighted ? kMaxMult : 1;
     bj.lstride = p.fine.lstride;
     bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
     if (p.L > 1) {
@@ -1246,6 +1271,7 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     w.coarse_level = level;
     w.min_known = csm_host_min_known(scan->n_points, prm->known_rate_threshold);
     w.score_threshold = prm->score_threshold;
+    w.merge_mode = merging_pays(scan->angles, scan->ranges, scan->n_points, geom->resolution) ? 0 : 1;
 
     /* Projection on the device with a per-entry certificate; the host
      * recomputes (glibc) only the entries that could not be certified. */
@@ -1582,6 +1608,11 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         if (!plan_pass(nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
             return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
                         spec.stride[h]);
+    {
+        const csm_loop_query& q0 = queries[idx[0]];
+        lp[0].weighted = merging_pays(q0.scan.angles, q0.scan.ranges, q0.scan.n_points,
+                                      q0.geometry.resolution);
+    }
     const int lstride = lp[0].lstride;
     const int ncb = lp[0].ncb();
 
@@ -1689,6 +1720,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.known_r0 = g.known_r0;
         B.known_c0 = g.known_c0;
         B.hash_size = bin_hash_size(p.n);
+        B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {

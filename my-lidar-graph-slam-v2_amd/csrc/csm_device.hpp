@@ -64,6 +64,7 @@ struct BinJob {
     int32_t x_hi, y_hi;        /* most positive candidate offset */
     int32_t tiles_x, tiles_y;
     int32_t hash_size;         /* power of two >= 4/3 n_points (LDS hash table of k_bin) */
+    int32_t max_mult;          /* kMaxMult: merge same-cell beams; 1: one entry per beam */
     int32_t lstride;
     /* first row / column of the map that holds a known cell: a box that ends
      * before it is unknown on every level, so reading it as unknown is right */

@@ -139,13 +139,15 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         atomicOr(job.flags, kFlagBandTouch);
     __syncthreads();
 
-    constexpr uint32_t max_mult = kMaxMult;
+    /* the host decides per query whether merging pays (job.max_mult 1 = off) */
+    const uint32_t max_mult = (uint32_t)job.max_mult;
 
     /* Pass B: entries per tile (a cell with more than max_mult beams is split) */
     for (int sl = tid; sl < job.hash_size; sl += kBlock) {
         const uint32_t key = hkey[sl];
         if (key)
-            atomicAdd(&hist[(key - 1u) >> 12], (hval[sl] + max_mult - 1) / max_mult);
+            atomicAdd(&hist[(key - 1u) >> 12],
+                      max_mult == 1u ? hval[sl] : (hval[sl] + kMaxMult - 1) / kMaxMult);
     }
     __syncthreads();
 
@@ -224,7 +226,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         const uint32_t rb = ((k1 >> 6) & 63u) - bb_rmin[tile];
         const uint32_t cb = (k1 & 63u) - bb_cmin[tile];
         uint32_t beams = hval[sl];
-        const uint32_t entries = (beams + max_mult - 1) / max_mult;
+        const uint32_t entries = max_mult == 1u ? beams : (beams + kMaxMult - 1) / kMaxMult;
         uint32_t pos = atomicAdd(&hist[tile], entries);
         for (; beams > 0; ++pos) {
             const uint32_t m = min(beams, max_mult);
@@ -269,8 +271,10 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 
 /* LSTRIDE: LDS row pitch in cells. R: candidate rows per lane.
  * MODE 0: candidates one cell apart; 1: `stride` = 2^k cells apart (coarser
- * levels); 2: any stride (e.g. LowResolutionMapWinSize 5). */
-template <int LSTRIDE, int R, int MODE>
+ * levels); 2: any stride (e.g. LowResolutionMapWinSize 5).
+ * WEIGHTED: entries carry beam multiplicities (k_bin merged same-cell beams);
+ * otherwise every entry is one beam and the multiply is dropped. */
+template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups,
                                            int slice, int n_slices, int n_buf)
 {
@@ -490,14 +494,22 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
             }
             return (STRIDED ? sm_cells + tb : base) + off;
         };
-        auto gather = [&](uint32_t pbv) {          /* weighted by the beam count */
-            const uint32_t m = STRIDED ? pbv >> 24 : pbv >> 16;
+        auto gather = [&](uint32_t pbv) {
             const uint32_t* p = locate(pbv);
+            if (WEIGHTED) {                        /* weighted by the beam count */
+                const uint32_t m = STRIDED ? pbv >> 24 : pbv >> 16;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                acc[r] = __umul24(p[r * LSTRIDE], m) + acc[r];
+                for (int r = 0; r < R; ++r)
+                    acc[r] = __umul24(p[r * LSTRIDE], m) + acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r] += p[r * LSTRIDE];
+            }
         };
-        auto mult_of = [&](uint32_t pbv) { return STRIDED ? pbv >> 24 : pbv >> 16; };
+        auto mult_of = [&](uint32_t pbv) {
+            return !WEIGHTED ? 1u : STRIDED ? pbv >> 24 : pbv >> 16;
+        };
         /* entries: 64 per LDS read, broadcast with v_readlane */
         uint32_t pb_cur = lpb[lane];
         for (int b0 = 0; b0 < cnt; b0 += 64) {
@@ -626,18 +638,18 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
 }
 
 /* grid = (candidate blocks, theta slices, tile slices) */
-template <int LSTRIDE, int R, int MODE>
+template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups, int n_buf)
 {
-    score_body<LSTRIDE, R, MODE>(job, cbx, groups, blockIdx.z, gridDim.z, n_buf);
+    score_body<LSTRIDE, R, MODE, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, n_buf);
 }
 
 /* grid = (candidate blocks, theta slices, jobs * n_slices) */
-template <int LSTRIDE, int R, int MODE>
+template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups,
                                                        int n_slices, int n_buf)
 {
-    score_body<LSTRIDE, R, MODE>(jobs[blockIdx.z / n_slices], cbx, groups,
+    score_body<LSTRIDE, R, MODE, WEIGHTED>(jobs[blockIdx.z / n_slices], cbx, groups,
                                     blockIdx.z % n_slices, n_slices, n_buf);
 }
 

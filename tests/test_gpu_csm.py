@@ -65,3 +65,26 @@ def test_config1_match_summary(gpu_ctx, oracle):
     assert (out["win_x"], out["win_y"], out["win_theta"]) == (lit["winX"], lit["winY"], lit["winT"])
     assert out["estimated_pose"] == lit["estimatedPose"]      # bit-exact doubles
     assert out["raw"]["score"] == lit["scoreMax"]
+
+
+@pytest.mark.parametrize("merge_mode", [0, 1])
+def test_beam_merging_on_and_off_give_identical_sums(gpu_ctx, oracle, merge_mode):
+    """k_bin either merges beams that share a cell into weighted entries or
+    keeps one entry per beam (csm_window.merge_mode); both must reproduce every
+    candidate's integer sums. Short ranges put many beams on one cell
+    (multiplicities above kMaxMult = 15 are split)."""
+    case = synth.csm_case(13, n_beams=4000, max_range=1.2)
+    rx, ry, rt, L = 0.8, 0.8, math.radians(8), 4
+    (wx, wy, wt), col, row, mk = _window_for(case, rx, ry, rt, L)
+    dup = max(np.unique(np.stack([col[wt], row[wt]]), axis=1, return_counts=True)[1])
+    assert dup > 15
+    gpu_ctx.upload_grid(2, case["grid"])
+    gpu_ctx.build_pyramid(2, [1, L])
+    w = gpu_ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, L, 1, mk, 0.0, merge_mode)
+    res, S, K, CK = gpu_ctx.score_window(2, w, col, row, dump=True)
+    want, oS, oK, oCK = oracle.csm_closed_form(case, rx, ry, rt, L, dump=True)
+    assert np.array_equal(S, oS) and np.array_equal(K, oK) and np.array_equal(CK, oCK)
+    lit = oracle.csm(case, rx, ry, rt, L)
+    assert (res["best_x"], res["best_y"], res["best_theta"]) == (lit["bestX"], lit["bestY"], lit["bestT"])
+    assert res["score"] == lit["scoreMax"]
+    gpu_ctx.release_grid(2)
