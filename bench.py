@@ -192,6 +192,7 @@ def main():
     coarse_ms, coarse_n = ctx.kernel_time("score_coarse")
     bin_ms, bin_n = ctx.kernel_time("bin")
     fin_ms, fin_n = ctx.kernel_time("finalize")
+    arg_ms, arg_n = ctx.kernel_time("argmax")
 
     # extra (not `value`): the same scans through the batched detector entry
     # (csm_correlative_match_batch: scans arrive as host arrays, projection on
@@ -278,6 +279,7 @@ def main():
                     "score_coarse": coarse_ms / max(1, coarse_n) * 1e3,
                     "bin": bin_ms / max(1, bin_n) * 1e3,
                     "finalize": fin_ms / max(1, fin_n) * 1e3,
+                    "argmax": arg_ms / max(1, arg_n) * 1e3,
                 },
             },
         }

@@ -67,7 +67,7 @@ struct csm_ctx {
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
-    DevBuf tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
+    DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -540,6 +540,21 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     if ((rc = ensure(ctx, ctx->best, nt * ncb * sizeof(BlockBest)))) return rc;
     if ((rc = ensure(ctx, ctx->sorted_rc, nt * p.n * 4))) return rc;
 
+    /* tile-split fine launch when the window gives fewer than ~1.5 workgroups
+     * per CU (config 2: 246); CSM_FINE_SLICES overrides for tuning */
+    int fine_slices = 1;
+    {
+        const long blocks = (long)ncb * p.n_theta;
+        if (blocks < 384)
+            fine_slices = (int)std::min<long>(4, std::max<long>(1, 492 / std::max<long>(1, blocks)));
+        if (const char* e = getenv("CSM_FINE_SLICES"))
+            fine_slices = std::max(1, std::min(8, atoi(e)));
+        if (fine_slices > 1) {
+            const size_t words = nt * (size_t)p.nx * p.ny;
+            if ((rc = ensure(ctx, ctx->fine_s, words * 4))) return rc;
+            if ((rc = ensure(ctx, ctx->fine_k, words * 4))) return rc;
+        }
+    }
     uint32_t* flag_words = reinterpret_cast<uint32_t*>(ctx->misc.p);
     if (!ctx->flags_ready) {
         HIP_TRY(ctx, hipMemsetAsync(flag_words, 0, 8, ctx->stream));
@@ -583,6 +598,11 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         bj.zero_a = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
         bj.zero_b = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
         bj.zero_words = p.nxc * p.nyc;
+    }
+    if (fine_slices > 1) {
+        bj.zero_c = reinterpret_cast<uint32_t*>(ctx->fine_s.p);
+        bj.zero_d = reinterpret_cast<uint32_t*>(ctx->fine_k.p);
+        bj.zero_words2 = p.nx * p.ny;
     }
     {
         const size_t lds = bin_lds_bytes(p.tiles_x * p.tiles_y, p.n);
@@ -635,6 +655,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     fj.ny = p.ny;
     fj.stride = 1;
     fj.block_best = reinterpret_cast<BlockBest*>(ctx->best.p);
+    (void)fine_slices;
     fj.rank_l = p.L;
     if (dumps) {
         fj.dump_s = dumps->dump_s;
@@ -651,7 +672,29 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     } else {
         fj.check_own_known = 1;
     }
-    {
+    if (fine_slices > 1) {
+        /* small windows: too few workgroups to fill the chip, so the tile list
+         * is split over blockIdx.z, the slices add their exact integer sums
+         * with atomics, and a second pass does the arg-max */
+        ScoreJob sj = fj;
+        sj.block_best = nullptr;
+        sj.dump_s = nullptr;
+        sj.dump_k = nullptr;
+        sj.acc_s = reinterpret_cast<uint32_t*>(ctx->fine_s.p);
+        sj.acc_k = reinterpret_cast<uint32_t*>(ctx->fine_k.p);
+        sj.acc_x_major = 1;
+        {
+            ScopedTimer tm(ctx, "score_fine");
+            if ((rc = launch_score(ctx, sj, p.fine, p.n_theta, fine_slices)))
+                return rc;
+        }
+        ScoreJob aj = fj;
+        aj.in_s = sj.acc_s;
+        aj.in_k = sj.acc_k;
+        ScopedTimer tm(ctx, "argmax");
+        if ((rc = launch_score(ctx, aj, p.fine, p.n_theta, 1)))
+            return rc;
+    } else {
         ScopedTimer tm(ctx, "score_fine");
         if ((rc = launch_score(ctx, fj, p.fine, p.n_theta, 1)))
             return rc;
@@ -886,7 +929,7 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
-                       &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
+                       &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
                        &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc };
     for (DevBuf* b : bufs)
         if (b->p)

@@ -88,6 +88,11 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             job.zero_a[(size_t)t * job.zero_words + i] = 0;
             job.zero_b[(size_t)t * job.zero_words + i] = 0;
         }
+    if (job.zero_c)
+        for (int i = tid; i < job.zero_words2; i += kBlock) {
+            job.zero_c[(size_t)t * job.zero_words2 + i] = 0;
+            job.zero_d[(size_t)t * job.zero_words2 + i] = 0;
+        }
     for (int i = tid; i < ntile; i += kBlock) {
         hist[i] = 0;
         bb_rmin[i] = kTile;
@@ -347,7 +352,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
 
     const int grid_rows = job.rows, grid_pitch = job.pitch;
     const uint16_t* __restrict__ cells = job.cells;
-    const int ntiles = job.n_tiles[t];
+    const int ntiles = job.in_s ? 0 : job.n_tiles[t];
     const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)t * job.n_points;
     /* chunks (8 cells, 16 B of the uint16 grid) one lane may have to fetch per tile */
@@ -545,6 +550,18 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
 
     /* ---- epilogue: dumps, eligibility, arg-max ---- */
     const int xi = bx * cbx + dxi;
+    if (job.in_s && lane_on && xi < job.nx) {
+        /* arg-max pass of a tile-split launch: the slices' sums are complete */
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yi = by * cby + g * R + r;
+            if (yi < job.ny) {
+                const size_t ai = ((size_t)t * job.ny + yi) * job.nx + xi;
+                S[r] = job.in_s[ai];
+                K[r] = job.in_k[ai];
+            }
+        }
+    }
     unsigned long long bkey = 0, brank = ~0ull;
     uint32_t bcnt = 0;
     bool bound_broken = false;
@@ -562,11 +579,13 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
             if (job.dump_k)
                 job.dump_k[ci] = (uint16_t)K[r];
             if (job.acc_s) {
-                /* tile-split launch: slices add their partial integer sums */
+                /* tile-split launch: slices add their partial integer sums.
+                 * acc_x_major: consecutive lanes (dx) hit consecutive words */
+                const size_t ai = job.acc_x_major ? ((size_t)t * job.ny + yi) * job.nx + xi : ci;
                 if (S[r])
-                    atomicAdd(&job.acc_s[ci], S[r]);
+                    atomicAdd(&job.acc_s[ai], S[r]);
                 if (K[r])
-                    atomicAdd(&job.acc_k[ci], K[r]);
+                    atomicAdd(&job.acc_k[ai], K[r]);
             }
             if (!job.block_best && !job.tie_list)
                 continue;
