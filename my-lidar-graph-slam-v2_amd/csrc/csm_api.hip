@@ -434,6 +434,27 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
     return CSM_OK;
 }
 
+#define ARGMAX_CASE(LS, RR)                                                            \
+    if (pp.lstride == LS && pp.R == RR) {                                              \
+        hipLaunchKernelGGL((k_argmax<LS, RR>), grid, dim3(kBlock), 0, ctx->stream, job, \
+                           pp.cbx, pp.groups);                                         \
+        launched = true;                                                               \
+    }
+
+int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta)
+{
+    const dim3 grid(pp.ncb(), n_theta, 1);
+    bool launched = false;
+    ARGMAX_CASE(96, 4) ARGMAX_CASE(96, 5) ARGMAX_CASE(96, 6) ARGMAX_CASE(96, 7) ARGMAX_CASE(96, 8)
+    ARGMAX_CASE(128, 4) ARGMAX_CASE(128, 5) ARGMAX_CASE(128, 6) ARGMAX_CASE(128, 7) ARGMAX_CASE(128, 8)
+    ARGMAX_CASE(160, 4) ARGMAX_CASE(160, 5) ARGMAX_CASE(160, 6) ARGMAX_CASE(160, 7) ARGMAX_CASE(160, 8)
+    ARGMAX_CASE(192, 4) ARGMAX_CASE(192, 5) ARGMAX_CASE(192, 6) ARGMAX_CASE(192, 7) ARGMAX_CASE(192, 8)
+    if (!launched)
+        return fail(ctx, CSM_EINVAL, "internal: no arg-max kernel for lstride %d R %d", pp.lstride, pp.R);
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
 int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const PassPlan& pp,
                        int n_theta_max, int n_slices)
 {
@@ -692,7 +713,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         aj.in_s = sj.acc_s;
         aj.in_k = sj.acc_k;
         ScopedTimer tm(ctx, "argmax");
-        if ((rc = launch_score(ctx, aj, p.fine, p.n_theta, 1)))
+        if ((rc = launch_argmax(ctx, aj, p.fine, p.n_theta)))
             return rc;
     } else {
         ScopedTimer tm(ctx, "score_fine");

@@ -663,6 +663,15 @@ __global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int gro
     score_body<LSTRIDE, R, MODE, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, n_buf);
 }
 
+/* The arg-max pass after a tile-split launch (job.in_s set): same lane <->
+ * candidate mapping and epilogue, no gathering. A kernel of its own so that
+ * profiles keep it apart from the gather launches. */
+template <int LSTRIDE, int R>
+__global__ __launch_bounds__(kBlock) void k_argmax(ScoreJob job, int cbx, int groups)
+{
+    score_body<LSTRIDE, R, 0, false>(job, cbx, groups, 0, 1, 1);
+}
+
 /* grid = (candidate blocks, theta slices, jobs * n_slices) */
 template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups,
