@@ -252,7 +252,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u16 cells, u32/u64 integer accumulate (f64 replay of the winner)",
+            "dtype": "u32",   # uint16 cells, exact u32/u64 integer sums; f64 replay of the winner
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: frontend CSM, 1080-beam scan, 400x400@5cm grid, "

@@ -571,9 +571,17 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         if (const char* e = getenv("CSM_FINE_SLICES"))
             fine_slices = std::max(1, std::min(8, atoi(e)));
         if (fine_slices > 1) {
+            /* the accumulators are zero between queries: cleared once when
+             * (re)allocated, then by the arg-max pass as it reads them */
             const size_t words = nt * (size_t)p.nx * p.ny;
+            const void* old_s = ctx->fine_s.p;
+            const void* old_k = ctx->fine_k.p;
             if ((rc = ensure(ctx, ctx->fine_s, words * 4))) return rc;
             if ((rc = ensure(ctx, ctx->fine_k, words * 4))) return rc;
+            if (ctx->fine_s.p != old_s)
+                HIP_TRY(ctx, hipMemsetAsync(ctx->fine_s.p, 0, ctx->fine_s.cap, ctx->stream));
+            if (ctx->fine_k.p != old_k)
+                HIP_TRY(ctx, hipMemsetAsync(ctx->fine_k.p, 0, ctx->fine_k.cap, ctx->stream));
         }
     }
     uint32_t* flag_words = reinterpret_cast<uint32_t*>(ctx->misc.p);
@@ -619,11 +627,6 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         bj.zero_a = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
         bj.zero_b = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
         bj.zero_words = p.nxc * p.nyc;
-    }
-    if (fine_slices > 1) {
-        bj.zero_c = reinterpret_cast<uint32_t*>(ctx->fine_s.p);
-        bj.zero_d = reinterpret_cast<uint32_t*>(ctx->fine_k.p);
-        bj.zero_words2 = p.nx * p.ny;
     }
     {
         const size_t lds = bin_lds_bytes(p.tiles_x * p.tiles_y, p.n);

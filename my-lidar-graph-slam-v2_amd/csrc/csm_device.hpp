@@ -58,9 +58,6 @@ struct BinJob {
     uint32_t* zero_a;          /* optional: [n_theta][zero_words] arrays this kernel clears */
     uint32_t* zero_b;          /*   (the coarse level's atomic accumulators)                */
     int32_t   zero_words;
-    uint32_t* zero_c;          /* same for the fine level's accumulators of a tile-split launch */
-    uint32_t* zero_d;
-    int32_t   zero_words2;
     int32_t n_theta, n_points, max_tiles;
     int32_t rows, cols;
     int32_t x_lo, y_lo;        /* most negative candidate offset */
@@ -97,9 +94,9 @@ struct ScoreJob {
     uint32_t*  acc_s;          /* [n_theta][nx][ny] atomic accumulate (tile-split launches) */
     uint32_t*  acc_k;
     int32_t    acc_x_major;    /* acc arrays laid out [n_theta][ny][nx] (coalesced atomics) */
-    const uint32_t* in_s;      /* [n_theta][ny][nx]; non-null: no gathering, the sums are read from here (the
+    uint32_t* in_s;            /* [n_theta][ny][nx]; non-null: no gathering, the sums are read from here (the
                                   arg-max pass after a tile-split launch) */
-    const uint32_t* in_k;
+    uint32_t* in_k;            /* (the pass clears what it has read) */
     BlockBest* block_best;     /* [n_theta][n_cand_blocks] */
     /* tie collection pass: append the rank of every eligible candidate whose
      * key equals *collect_key */

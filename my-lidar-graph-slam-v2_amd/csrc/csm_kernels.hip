@@ -88,11 +88,6 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             job.zero_a[(size_t)t * job.zero_words + i] = 0;
             job.zero_b[(size_t)t * job.zero_words + i] = 0;
         }
-    if (job.zero_c)
-        for (int i = tid; i < job.zero_words2; i += kBlock) {
-            job.zero_c[(size_t)t * job.zero_words2 + i] = 0;
-            job.zero_d[(size_t)t * job.zero_words2 + i] = 0;
-        }
     for (int i = tid; i < ntile; i += kBlock) {
         hist[i] = 0;
         bb_rmin[i] = kTile;
@@ -559,6 +554,9 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                 const size_t ai = ((size_t)t * job.ny + yi) * job.nx + xi;
                 S[r] = job.in_s[ai];
                 K[r] = job.in_k[ai];
+                /* leave the accumulators clean for the next query */
+                job.in_s[ai] = 0;
+                job.in_k[ai] = 0;
             }
         }
     }
