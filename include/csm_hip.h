@@ -18,6 +18,9 @@
  *    1..65535 <-> P in [0.001, 0.999] (inc/grid_map_new/grid_binary_bayes.hpp:163-176).
  *  - there is no CPU fallback: without a GPU every compute entry point fails
  *    with CSM_ENODEV.
+ *  - limits: at most 12288 beams per scan; LowResolution / 2^NodeHeightMax up
+ *    to 64 cells; grid + window up to ~2500 x 2500 cells per map (CSM_EINVAL
+ *    beyond).
  */
 #ifndef CSM_HIP_H
 #define CSM_HIP_H

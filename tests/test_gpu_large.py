@@ -90,3 +90,36 @@ def test_loop_detector_correlative_default_settings(gpu_ctx, oracle):
     assert found == want_found
     for k in grids:
         gpu_ctx.release_grid(k)
+
+
+def test_config3_batch_of_256_submaps_sampled_against_oracle(gpu_ctx, oracle):
+    """configs[2]: 1 scan (1080 beams) vs 256 candidate submaps, 3-level grids
+    (H = 2), 2.5 m x 2.5 m x 0.5 rad, thresholds 0.55 / 0.6, through the sharding
+    detector class (world size 1 here). Every 16th query is checked against the
+    literal CPU search; all records must be self-consistent."""
+    n = 256
+    rng = np.random.RandomState(3)
+    queries, grids, cases = [], {}, []
+    for i in range(n):
+        c = synth.csm_case(1000 + i, n_beams=1080, fov=1.5 * math.pi)
+        c["init_pose"] = tuple(np.asarray(c["truth"]) + rng.uniform(-0.6, 0.6, 3) * (1, 1, 0.15))
+        cases.append(c)
+        grids[20000 + i] = c["grid"]
+        queries.append(dict(map_id=20000 + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+                            rel_pose=(0.0, 0.0, 0.0), init_pose=c["init_pose"]))
+    det = parallel.LoopDetectorBranchBoundHIP("ld", gpu_ctx, 2.5, 2.5, 0.5, 2, 0.55, 0.6)
+    records, found = det.detect(queries, grids)
+    assert len(records) == n
+    assert found == [i for i, r in enumerate(records) if r["found"]]
+    for r in records:
+        assert r["key"] == 32268 * r["known"] + 499 * r["sum_values"]
+        if r["found"]:
+            assert r["score"] > 0.55 and r["known"] / 1080 > 0.6
+    for i in range(0, n, 16):
+        want = oracle.bnb(cases[i], 2.5, 2.5, 0.5, 2, 0.55, 0.6)
+        r = records[i]
+        assert r["found"] == want["found"]
+        assert (r["best_x"], r["best_y"], r["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"])
+        assert r["score"] == want["scoreMax"]
+    for k in grids:
+        gpu_ctx.release_grid(k)
