@@ -186,8 +186,6 @@ bool merging_pays(const double* angles, const double* ranges, int n, double res)
 }
 
 /* k_bin's LDS: 6 per-tile arrays, 2 * kBlock scan words, hash keys + values */
-int n_points_max_for_hash(int n) { return n; }
-
 int bin_hash_size(int n_points)
 {
     int h = 1024;
@@ -1640,7 +1638,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y) + p.n / kPbMax + 1;
         if (p.n > kMaxPoints)
             return fail(ctx, CSM_EINVAL, "query %d: more than %d beams per scan", idx[k], kMaxPoints);
-        bin_lds = std::max(bin_lds, bin_lds_bytes(p.tiles_x * p.tiles_y, n_points_max_for_hash(p.n)));
+        bin_lds = std::max(bin_lds, bin_lds_bytes(p.tiles_x * p.tiles_y, p.n));
         p.hit_off = hit_total;
         p.tile_off = tile_total;
         p.theta_off = theta_total;
