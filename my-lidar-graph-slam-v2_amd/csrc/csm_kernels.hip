@@ -1110,8 +1110,23 @@ __device__ __forceinline__ void proj_body(const ProjJob& job)
     job.hit_row[idx] = row;
     bool uncertain = !(qx - fx > mx && qx - fx < 1.0 - mx && qy - fy > my && qy - fy < 1.0 - my);
     if (job.check_nodes && !uncertain) {
-        /* appendNode's pose (scan_matcher_branch_bound.cpp:156-176) */
-        for (int xi = 0; xi < job.nx && !uncertain; ++xi) {
+        /* appendNode's pose (scan_matcher_branch_bound.cpp:156-176):
+         * floor(((sensor + x*step) + r*trig - off) / res) must equal base + x for
+         * every node offset x. The search step IS the resolution
+         * (scan_matcher_branch_bound.cpp:293-312), so in exact arithmetic the
+         * node coordinate is q + x; every rounding on the way is bounded, hence
+         * one test per beam and axis certifies all offsets at once. Only beams
+         * within that (slightly wider) margin of a cell edge walk the offsets. */
+        const double xr = fmax(fabs((double)job.x_lo), fabs((double)(job.x_lo + job.nx - 1))) * job.step_x;
+        const double yr = fmax(fabs((double)job.y_lo), fabs((double)(job.y_lo + job.ny - 1))) * job.step_y;
+        const double wx = 64.0 * ((fabs(r) * 8e-16 + (fabs(hx) + xr + fabs(job.off_x)) * 8e-16) / job.res +
+                                  (fabs(qx) + xr / job.res) * 8e-16);
+        const double wy = 64.0 * ((fabs(r) * 8e-16 + (fabs(hy) + yr + fabs(job.off_y)) * 8e-16) / job.res +
+                                  (fabs(qy) + yr / job.res) * 8e-16);
+        const bool unit_step = job.step_x == job.res && job.step_y == job.res;
+        const bool sure_x = unit_step && qx - fx > wx && qx - fx < 1.0 - wx;
+        const bool sure_y = unit_step && qy - fy > wy && qy - fy < 1.0 - wy;
+        for (int xi = 0; xi < job.nx && !sure_x && !uncertain; ++xi) {
             const int x = job.x_lo + xi;
             const double h = (job.sensor_x + x * job.step_x) + rc;
             const double q = (h - job.off_x) / job.res;
@@ -1119,7 +1134,7 @@ __device__ __forceinline__ void proj_body(const ProjJob& job)
             const double m = 64.0 * proj_err_bound(r, h, job.off_x, job.res, q);
             uncertain = !((int)f == col + x && q - f > m && q - f < 1.0 - m);
         }
-        for (int yi = 0; yi < job.ny && !uncertain; ++yi) {
+        for (int yi = 0; yi < job.ny && !sure_y && !uncertain; ++yi) {
             const int y = job.y_lo + yi;
             const double h = (job.sensor_y + y * job.step_y) + rs;
             const double q = (h - job.off_y) / job.res;
