@@ -73,6 +73,8 @@ struct csm_ctx {
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
                                      clears the word of query i + 1 */
     bool flags_ready = false;
+    bool fine_acc_dirty = false;  /* a tile-split launch was issued but its arg-max pass (which
+                                     clears the accumulators) was not: clear before reuse */
     int timing = 0;               /* 0 off, 1 every kernel, 2 the fine scoring kernel only */
     std::map<std::string, KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
@@ -576,10 +578,11 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
             const void* old_k = ctx->fine_k.p;
             if ((rc = ensure(ctx, ctx->fine_s, words * 4))) return rc;
             if ((rc = ensure(ctx, ctx->fine_k, words * 4))) return rc;
-            if (ctx->fine_s.p != old_s)
+            if (ctx->fine_s.p != old_s || ctx->fine_acc_dirty)
                 HIP_TRY(ctx, hipMemsetAsync(ctx->fine_s.p, 0, ctx->fine_s.cap, ctx->stream));
-            if (ctx->fine_k.p != old_k)
+            if (ctx->fine_k.p != old_k || ctx->fine_acc_dirty)
                 HIP_TRY(ctx, hipMemsetAsync(ctx->fine_k.p, 0, ctx->fine_k.cap, ctx->stream));
+            ctx->fine_acc_dirty = false;
         }
     }
     uint32_t* flag_words = reinterpret_cast<uint32_t*>(ctx->misc.p);
@@ -705,6 +708,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         sj.acc_s = reinterpret_cast<uint32_t*>(ctx->fine_s.p);
         sj.acc_k = reinterpret_cast<uint32_t*>(ctx->fine_k.p);
         sj.acc_x_major = 1;
+        ctx->fine_acc_dirty = true;
         {
             ScopedTimer tm(ctx, "score_fine");
             if ((rc = launch_score(ctx, sj, p.fine, p.n_theta, fine_slices)))
@@ -716,6 +720,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         ScopedTimer tm(ctx, "argmax");
         if ((rc = launch_argmax(ctx, aj, p.fine, p.n_theta)))
             return rc;
+        ctx->fine_acc_dirty = false;
     } else {
         ScopedTimer tm(ctx, "score_fine");
         if ((rc = launch_score(ctx, fj, p.fine, p.n_theta, 1)))
