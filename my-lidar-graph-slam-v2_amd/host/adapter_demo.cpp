@@ -4,7 +4,8 @@
  * reference-side ScanMatcher / LoopDetector subclass would.
  *
  * case file (little endian):
- *   int32 mode(0 csm, 1 bnb), rows, cols, n, n_queries, param_i (L or H)
+ *   int32 mode(0 csm, 1 bnb loop detector, 2 correlative loop detector), rows, cols, n,
+ *         n_queries, param_i (L or H)
  *   double res, offX, offY, rangeX, rangeY, rangeT, scoreThr, knownThr
  *   double rel[3]; double init[3 * n_queries]; double angles[n]; double ranges[n]
  *   uint16 grid[rows * cols]
@@ -68,8 +69,11 @@ int main(int argc, char** argv)
                     r.mEstimatedPose.mTheta, r.mScoreValue, r.mWinSizeX, r.mWinSizeY, r.mWinSizeTheta);
         return 0;
     }
-    auto d = LoopDetectorBranchBoundHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7]);
-    if (!d) {
+    auto d = mode == 1 ? LoopDetectorBranchBoundHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7])
+                       : nullptr;
+    auto dc = mode == 2 ? LoopDetectorCorrelativeHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7])
+                        : nullptr;
+    if (!d && !dc) {
         std::printf("{\"error\": \"no device\"}\n");
         return 3;
     }
@@ -85,7 +89,7 @@ int main(int argc, char** argv)
         q.mQueryScanNodeId = i;
         qs.push_back(q);
     }
-    const LoopDetectionResultVector rs = d->Detect(qs);
+    const LoopDetectionResultVector rs = d ? d->Detect(qs) : dc->Detect(qs);
     std::printf("{\"results\": [");
     for (size_t i = 0; i < rs.size(); ++i)
         std::printf("%s{\"node\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\"}", i ? ", " : "",

@@ -6,6 +6,8 @@
  *        inc/mapping/scan_matcher_correlative.hpp:53-125, scan_matcher.hpp:89-117
  *   LoopDetectorBranchBoundHIP  <- LoopDetectorBranchBound (search part)
  *        inc/mapping/loop_detector_branch_bound.hpp:71-112, loop_detector.hpp:97-116
+ *   LoopDetectorCorrelativeHIP  <- LoopDetectorCorrelative (search part)
+ *        inc/mapping/loop_detector_correlative.hpp, src/mapping/loop_detector_correlative.cpp:59-156
  *
  * The reference headers cannot be included in this image (Eigen3 / Boost are
  * absent), so the few value types the interfaces use are restated here in
@@ -335,6 +337,88 @@ private:
 
     const std::string mName;
     const int mNodeHeightMax;
+    const double mRangeX, mRangeY, mRangeTheta;
+    const double mScoreThreshold, mKnownRateThreshold;
+    detail::CtxPtr mCtx;
+};
+
+/* LoopDetectorCorrelative (the reference's default "RealTimeCorrelative" loop
+ * detector, launcher_settings_default.json:101-114, 394): the correlative
+ * matcher with the detector's thresholds, one coarse map cached per local map. */
+class LoopDetectorCorrelativeHIP final {
+public:
+    static std::unique_ptr<LoopDetectorCorrelativeHIP> Create(
+        const std::string& loopDetectorName, int lowResolution, double rangeX, double rangeY,
+        double rangeTheta, double scoreThreshold, double knownRateThreshold, int deviceId = 0)
+    {
+        /* src/mapping/loop_detector_correlative.cpp:38-56 */
+        if (!(scoreThreshold > 0.0 && scoreThreshold <= 1.0) ||
+            !(knownRateThreshold > 0.0 && knownRateThreshold <= 1.0) || lowResolution < 1)
+            return nullptr;
+        detail::CtxPtr ctx = detail::MakeContext(deviceId);
+        if (!ctx)
+            return nullptr;
+        return std::unique_ptr<LoopDetectorCorrelativeHIP>(new LoopDetectorCorrelativeHIP(
+            loopDetectorName, lowResolution, rangeX, rangeY, rangeTheta, scoreThreshold,
+            knownRateThreshold, std::move(ctx)));
+    }
+
+    const std::string& Name() const { return this->mName; }
+
+    LoopDetectionResultVector Detect(const LoopDetectionQueryVector& queries)
+    {
+        LoopDetectionResultVector results;
+        if (queries.empty())
+            return results;
+        csm_ctx* ctx = this->mCtx.get();
+        std::vector<csm_loop_query> flat(queries.size());
+        for (std::size_t i = 0; i < queries.size(); ++i) {
+            const LoopDetectionQuery& q = queries[i];
+            const GridMapView& g = q.mReferenceLocalMap;
+            if (!csm_has_grid(ctx, g.mId))
+                CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, g.mId, g.mValues, g.mRows, g.mCols));
+            csm_loop_query& f = flat[i];
+            f.map_id = g.mId;
+            f.geometry = { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
+            f.scan = detail::ToScan(q.mQueryScanData);
+            const double start[3] = { q.mReferenceLocalMapNodeGlobalPose.mX,
+                                      q.mReferenceLocalMapNodeGlobalPose.mY,
+                                      q.mReferenceLocalMapNodeGlobalPose.mTheta };
+            const double end[3] = { q.mQueryScanNodeGlobalPose.mX, q.mQueryScanNodeGlobalPose.mY,
+                                    q.mQueryScanNodeGlobalPose.mTheta };
+            csm_host_inverse_compound(start, end, f.initial_pose);
+        }
+        csm_correlative_params prm {};
+        prm.range_x = this->mRangeX;
+        prm.range_y = this->mRangeY;
+        prm.range_theta = this->mRangeTheta;
+        prm.low_resolution = this->mLowResolution;
+        prm.score_threshold = this->mScoreThreshold;
+        prm.known_rate_threshold = this->mKnownRateThreshold;
+        std::vector<csm_summary> out(queries.size());
+        CSM_ASSERT_OK(ctx, csm_correlative_match_batch(
+                               ctx, flat.data(), static_cast<std::int32_t>(flat.size()), &prm, out.data()));
+        for (std::size_t i = 0; i < queries.size(); ++i) {
+            if (!out[i].pose_found)
+                continue;
+            results.push_back(LoopDetectionResult {
+                { out[i].estimated_pose[0], out[i].estimated_pose[1], out[i].estimated_pose[2] },
+                queries[i].mReferenceLocalMapNodeGlobalPose, queries[i].mReferenceLocalMap.mId,
+                queries[i].mQueryScanNodeId, out[i].raw.score, out[i].raw.flags });
+        }
+        return results;
+    }
+
+private:
+    LoopDetectorCorrelativeHIP(const std::string& name, int lowResolution, double rangeX,
+                               double rangeY, double rangeTheta, double scoreThreshold,
+                               double knownRateThreshold, detail::CtxPtr ctx) :
+        mName(name), mLowResolution(lowResolution), mRangeX(rangeX), mRangeY(rangeY),
+        mRangeTheta(rangeTheta), mScoreThreshold(scoreThreshold),
+        mKnownRateThreshold(knownRateThreshold), mCtx(std::move(ctx)) { }
+
+    const std::string mName;
+    const int mLowResolution;
     const double mRangeX, mRangeY, mRangeTheta;
     const double mScoreThreshold, mKnownRateThreshold;
     detail::CtxPtr mCtx;

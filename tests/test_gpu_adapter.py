@@ -70,3 +70,25 @@ def test_cpp_loop_detector_adapter(tmp_path, oracle):
     for g, w in zip(got, want):
         assert [float.fromhex(v) for v in g["pose"]] == w[1]
         assert float.fromhex(g["score"]) == w[2]
+
+
+def test_cpp_loop_detector_correlative_adapter(tmp_path, oracle):
+    case = synth.csm_case(21, init_error=(0.4, -0.3, 0.06))
+    rng = np.random.RandomState(10)
+    inits = [tuple(np.asarray(case["truth"]) + rng.uniform(-0.5, 0.5, 3) * (1, 1, 0.2)) for _ in range(4)]
+    inits.append((-30.0, 30.0, 0.0))     # off the map
+    p = str(tmp_path / "ldc.bin")
+    _write_case(p, 2, case, inits, 5, (2.5, 2.5, 0.5), (0.3, 0.5))
+    got = _run(p)["results"]
+    want = []
+    for i, init in enumerate(inits):
+        c = dict(case)
+        c["init_pose"] = init
+        r = oracle.csm(c, 2.5, 2.5, 0.5, 5, 0.3, 0.5)
+        if r["found"]:
+            want.append((i, r["estimatedPose"], r["scoreMax"]))
+    assert want, "test data should produce at least one detection"
+    assert [g["node"] for g in got] == [w[0] for w in want]
+    for g, w in zip(got, want):
+        assert [float.fromhex(v) for v in g["pose"]] == w[1]
+        assert float.fromhex(g["score"]) == w[2]
