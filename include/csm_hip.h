@@ -265,6 +265,26 @@ int  csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
                                  int32_t n_queries, const csm_correlative_params* params,
                                  csm_summary* out);
 
+/* ScanMatcherGridSearch constructor arguments + thresholds
+ * (inc/mapping/scan_matcher_grid_search.hpp, src/scan_matcher_factory.cpp) */
+typedef struct {
+    double range_x, range_y, range_theta;
+    double step_x, step_y, step_theta;
+    double score_threshold;
+    double known_rate_threshold;
+} csm_grid_search_params;
+
+/* ScanMatcherGridSearch::OptimizePose, both overloads
+ * (src/mapping/scan_matcher_grid_search.cpp:69-190): brute force over
+ * accumulated-double offsets, every pose projected on its own
+ * (ScorePixelAccurate::Score), a pose counts only if its own known rate passes.
+ * In the summary win_x / win_y / win_theta hold the number of x / y / theta
+ * offsets and raw.best_x / best_y / best_theta the winner's loop indices
+ * (-1 when nothing was found). */
+int  csm_grid_search_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geom,
+                           const csm_scan* scan, const double initial_pose[3],
+                           const csm_grid_search_params* params, csm_summary* out);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* enable = 1: every kernel launch is bracketed by HIP events on the ctx
  * stream; enable = 2: only the dominant (fine-level) scoring kernel, to keep

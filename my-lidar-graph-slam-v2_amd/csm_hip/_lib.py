@@ -55,6 +55,12 @@ class BnbParams(C.Structure):
                 ("known_rate_threshold", C.c_double)]
 
 
+class GridSearchParams(C.Structure):
+    _fields_ = [("range_x", C.c_double), ("range_y", C.c_double), ("range_theta", C.c_double),
+                ("step_x", C.c_double), ("step_y", C.c_double), ("step_theta", C.c_double),
+                ("score_threshold", C.c_double), ("known_rate_threshold", C.c_double)]
+
+
 class Result(C.Structure):
     _fields_ = [("found", C.c_int32), ("best_x", C.c_int32),
                 ("best_y", C.c_int32), ("best_theta", C.c_int32),
@@ -127,6 +133,8 @@ SIGNATURES = {
                                       _P(BnbParams), _P(Summary)]),
     "csm_correlative_match_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32,
                                               _P(CorrelativeParams), _P(Summary)]),
+    "csm_grid_search_match": (C.c_int, [_ctx, C.c_uint64, _P(Geometry), _P(Scan), C.c_void_p,
+                                        _P(GridSearchParams), _P(Summary)]),
     "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),
     "csm_kernel_time": (C.c_int, [_ctx, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "csm_reset_kernel_timing": (C.c_int, [_ctx]),

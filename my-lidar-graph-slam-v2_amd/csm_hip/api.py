@@ -220,6 +220,26 @@ class Context:
                                                    _ptr(init), C.byref(p), C.byref(out)))
         return summary_to_dict(out)
 
+    def grid_search_match(self, map_id, geom, angles, ranges, rel_pose, init_pose,
+                          range_x, range_y, range_theta, step_x, step_y, step_theta,
+                          score_threshold=0.0, known_rate_threshold=0.0):
+        """ScanMatcherGridSearch::OptimizePose
+        (src/my_lidar_graph_slam/mapping/scan_matcher_grid_search.cpp:69-190)."""
+        a, r = _f64(angles), _f64(ranges)
+        scan = L.Scan()
+        scan.angles = a.ctypes.data_as(C.POINTER(C.c_double))
+        scan.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
+        scan.n_points = a.size
+        scan.relative_sensor_pose[:] = list(rel_pose)
+        g = L.Geometry(*geom)
+        p = L.GridSearchParams(range_x, range_y, range_theta, step_x, step_y, step_theta,
+                               score_threshold, known_rate_threshold)
+        init = _f64(init_pose)
+        out = L.Summary()
+        self._check(self.lib.csm_grid_search_match(self._ctx, map_id, C.byref(g), C.byref(scan),
+                                                   _ptr(init), C.byref(p), C.byref(out)))
+        return summary_to_dict(out)
+
     def _flatten_queries(self, queries):
         n = len(queries)
         arr = (L.LoopQuery * n)()
@@ -309,6 +329,33 @@ class ScanMatcherCorrelativeHIP:
         out = self.ctx.correlative_match(mid, geom, angles, ranges, rel_pose, init_pose,
                                          self.range_x, self.range_y, self.range_theta,
                                          self.low_resolution, score_threshold,
+                                         known_rate_threshold)
+        if map_id is None:
+            self.ctx.release_grid(mid)
+        return out
+
+
+class ScanMatcherGridSearchHIP:
+    """Drop-in for ScanMatcherGridSearch (constructor arguments as in
+    src/my_lidar_graph_slam/scan_matcher_factory.cpp, "GridSearch" branch:
+    ranges then steps)."""
+
+    def __init__(self, name, range_x, range_y, range_theta, step_x, step_y, step_theta, ctx=None):
+        if not (step_x > 0 and step_y > 0 and step_theta > 0):
+            raise ValueError("steps must be positive")
+        self.name = name
+        self.ranges = (range_x, range_y, range_theta)
+        self.steps = (step_x, step_y, step_theta)
+        self.ctx = ctx or Context()
+        self._nonce = (1 << 62) + 1
+
+    def optimize_pose(self, grid, geom, angles, ranges, rel_pose, init_pose,
+                      map_id=None, score_threshold=0.0, known_rate_threshold=0.0):
+        mid = self._nonce if map_id is None else map_id
+        if grid is not None and (map_id is None or not self.ctx.has_grid(mid)):
+            self.ctx.upload_grid(mid, grid)
+        out = self.ctx.grid_search_match(mid, geom, angles, ranges, rel_pose, init_pose,
+                                         *self.ranges, *self.steps, score_threshold,
                                          known_rate_threshold)
         if map_id is None:
             self.ctx.release_grid(mid)

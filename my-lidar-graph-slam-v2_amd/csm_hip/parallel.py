@@ -146,3 +146,30 @@ class LoopDetectorCorrelativeHIP:
             queries, self.ranges[0], self.ranges[1], self.ranges[2], self.low_resolution,
             self.score_threshold, self.known_rate_threshold) if queries else []
         return outs, [i for i, o in enumerate(outs) if o["pose_found"]]
+
+
+class LoopDetectorGridSearchHIP:
+    """Search part of LoopDetectorGridSearch::Detect
+    (src/my_lidar_graph_slam/mapping/loop_detector_grid_search.cpp:52-156): the
+    brute-force matcher with the detector's two thresholds, one query after the
+    other as the reference runs them."""
+
+    def __init__(self, name, ctx, range_x, range_y, range_theta, step_x, step_y, step_theta,
+                 score_threshold, known_rate_threshold):
+        if not (0.0 < score_threshold <= 1.0 and 0.0 < known_rate_threshold <= 1.0):
+            raise ValueError("thresholds must lie in (0, 1]")   # loop_detector_grid_search.cpp:47-48
+        self.name = name
+        self.ctx = ctx
+        self.window = (range_x, range_y, range_theta, step_x, step_y, step_theta)
+        self.score_threshold = score_threshold
+        self.known_rate_threshold = known_rate_threshold
+
+    def detect(self, queries, grids=None):
+        outs = []
+        for q in queries:
+            if not self.ctx.has_grid(q["map_id"]):
+                self.ctx.upload_grid(q["map_id"], grids[q["map_id"]])
+            outs.append(self.ctx.grid_search_match(
+                q["map_id"], q["geom"], q["angles"], q["ranges"], q["rel_pose"], q["init_pose"],
+                *self.window, self.score_threshold, self.known_rate_threshold))
+        return outs, [i for i, o in enumerate(outs) if o["pose_found"]]

@@ -2104,6 +2104,126 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
     return CSM_OK;
 }
 
+/* ScanMatcherGridSearch::OptimizePose (scan_matcher_grid_search.cpp:69-190) */
+int csm_grid_search_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geom,
+                          const csm_scan* scan, const double initial_pose[3],
+                          const csm_grid_search_params* prm, csm_summary* out)
+{
+    if (!ctx || !geom || !scan || !initial_pose || !prm || !out || scan->n_points < 1 ||
+        !(prm->step_x > 0.0) || !(prm->step_y > 0.0) || !(prm->step_theta > 0.0))
+        return fail(ctx, CSM_EINVAL, "csm_grid_search_match: bad arguments");
+    DeviceGrid* g = find_grid(ctx, map_id);
+    if (!g)
+        return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof(*out));
+    const auto t0 = std::chrono::steady_clock::now();
+    csm_host_compound(initial_pose, scan->relative_sensor_pose, out->sensor_pose);
+    /* the three loops of scan_matcher_grid_search.cpp:118-120: accumulated doubles */
+    const double rx = prm->range_x / 2.0, ry = prm->range_y / 2.0, rt = prm->range_theta / 2.0;
+    std::vector<double> px, py, th;
+    for (double dy = -ry; dy <= ry; dy += prm->step_y)
+        py.push_back(out->sensor_pose[1] + dy);
+    for (double dx = -rx; dx <= rx; dx += prm->step_x)
+        px.push_back(out->sensor_pose[0] + dx);
+    for (double dt = -rt; dt <= rt; dt += prm->step_theta)
+        th.push_back(out->sensor_pose[2] + dt);
+    const int nx = (int)px.size(), ny = (int)py.size(), nt = (int)th.size(), n = scan->n_points;
+    out->win_x = nx;
+    out->win_y = ny;
+    out->win_theta = nt;
+    out->step_x = prm->step_x;
+    out->step_y = prm->step_y;
+    out->step_theta = prm->step_theta;
+    for (int k = 0; k < 3; ++k)
+        out->best_sensor_pose[k] = out->sensor_pose[k];
+    out->raw.best_x = out->raw.best_y = out->raw.best_theta = -1;
+    out->raw.score = prm->score_threshold;
+    const size_t total = (size_t)nx * ny * nt;
+    out->candidates = (int64_t)total;
+    if (total > 0) {
+        /* ScanData::HitPoint's products per theta value, with glibc */
+        std::vector<double> prod(2 * (size_t)nt * n);
+        double* rc = prod.data();
+        double* rs = rc + (size_t)nt * n;
+        for (int k = 0; k < nt; ++k)
+            for (int i = 0; i < n; ++i) {
+                rc[(size_t)k * n + i] = scan->ranges[i] * std::cos(th[k] + scan->angles[i]);
+                rs[(size_t)k * n + i] = scan->ranges[i] * std::sin(th[k] + scan->angles[i]);
+            }
+        int rc_ = 0;
+        const size_t words = (size_t)nx + ny + prod.size();
+        if ((rc_ = ensure(ctx, ctx->ex_coarse, words * 8 + 64))) return rc_;
+        if ((rc_ = ensure(ctx, ctx->ex_fine, total * 8))) return rc_;
+        if ((rc_ = ensure(ctx, ctx->ex_fine_k, total * 4))) return rc_;
+        if ((rc_ = ensure(ctx, ctx->tie, 64))) return rc_;
+        double* d_px = reinterpret_cast<double*>(ctx->ex_coarse.p);
+        double* d_py = d_px + nx;
+        double* d_rc = d_py + ny;
+        double* d_rs = d_rc + (size_t)nt * n;
+        unsigned long long* d_best = reinterpret_cast<unsigned long long*>(ctx->tie.p);
+        const unsigned long long init_best[2] = { 0ull, ~0ull };
+        HIP_TRY(ctx, hipMemcpyAsync(d_px, px.data(), (size_t)nx * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_py, py.data(), (size_t)ny * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_rc, prod.data(), prod.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_best, init_best, 16, hipMemcpyHostToDevice, ctx->stream));
+        GridSearchJob gj;
+        std::memset(&gj, 0, sizeof(gj));
+        gj.cells = g->levels[0].cells;
+        gj.rows = g->rows;
+        gj.cols = g->cols;
+        gj.pitch = g->pitch;
+        gj.px = d_px;
+        gj.py = d_py;
+        gj.r_cos = d_rc;
+        gj.r_sin = d_rs;
+        gj.off_x = geom->offset_x;
+        gj.off_y = geom->offset_y;
+        gj.res = geom->resolution;
+        gj.nx = nx;
+        gj.ny = ny;
+        gj.nt = nt;
+        gj.n_points = n;
+        gj.min_known = csm_host_min_known(n, prm->known_rate_threshold);
+        gj.score_thr = prm->score_threshold;
+        gj.lut = ctx->lut_dev;
+        gj.out_score = reinterpret_cast<double*>(ctx->ex_fine.p);
+        gj.out_k = reinterpret_cast<uint32_t*>(ctx->ex_fine_k.p);
+        gj.best_bits = d_best;
+        gj.best_index = d_best + 1;
+        const unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock);
+        {
+            ScopedTimer tm(ctx, "grid_search");
+            hipLaunchKernelGGL(k_grid_scores, dim3(blocks), dim3(kBlock), 0, ctx->stream, gj);
+            hipLaunchKernelGGL(k_grid_pick, dim3(blocks), dim3(kBlock), 0, ctx->stream, gj);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        unsigned long long best[2] = { 0, 0 };
+        HIP_TRY(ctx, hipMemcpyAsync(best, d_best, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (best[0] != 0ull && best[1] != ~0ull) {
+            double score;
+            const unsigned long long bits = best[0] - 1ull;
+            std::memcpy(&score, &bits, 8);
+            const size_t p = (size_t)best[1];
+            const int it = (int)(p % nt), ix = (int)((p / nt) % nx), iy = (int)(p / ((size_t)nt * nx));
+            out->pose_found = 1;
+            out->raw.found = 1;
+            out->raw.best_x = ix;
+            out->raw.best_y = iy;
+            out->raw.best_theta = it;
+            out->raw.score = score;
+            out->best_sensor_pose[0] = px[ix];
+            out->best_sensor_pose[1] = py[iy];
+            out->best_sensor_pose[2] = th[it];
+        }
+    }
+    csm_host_move_backward(out->best_sensor_pose, scan->relative_sensor_pose, out->estimated_pose);
+    out->optimization_us =
+        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return CSM_OK;
+}
+
 /* ---- measurement hooks ---- */
 
 int csm_enable_kernel_timing(csm_ctx* ctx, int32_t enable)

@@ -211,5 +211,25 @@ struct LiteralJob {
     void* out;                     /* csm_result* */
 };
 
+/* Brute-force grid search (ScanMatcherGridSearch): every pose is projected on
+ * its own in double, from host-computed r*cos / r*sin per theta value. */
+struct GridSearchJob {
+    const uint16_t* cells;
+    int32_t rows, cols, pitch;
+    const double* px;          /* [nx] sensor x + dx (accumulated doubles, host) */
+    const double* py;          /* [ny] */
+    const double* r_cos;       /* [nt][n_points] */
+    const double* r_sin;
+    double off_x, off_y, res;
+    int32_t nx, ny, nt, n_points;
+    int32_t min_known;
+    double score_thr;
+    const double* lut;
+    double*   out_score;       /* [ny][nx][nt] traversal order */
+    uint32_t* out_k;
+    unsigned long long* best_bits;   /* [1] max score (as ordered bits) among eligible poses */
+    unsigned long long* best_index;  /* [1] first pose index reaching it */
+};
+
 } /* namespace csm */
 #endif

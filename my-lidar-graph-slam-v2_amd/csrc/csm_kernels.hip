@@ -1063,6 +1063,56 @@ __global__ __launch_bounds__(64) void k_csm_literal_scan(LiteralJob job)
     }
 }
 
+/* ------------------------------------------------------------------ grid search */
+/* ScanMatcherGridSearch (src/mapping/scan_matcher_grid_search.cpp:84-142): one
+ * lane per pose (dy, dx, dt); ScorePixelAccurate::Score for that pose in f64,
+ * beam order. Lanes run over dx fastest so a wave shares one theta's products. */
+__global__ __launch_bounds__(kBlock) void k_grid_scores(GridSearchJob job)
+{
+    const long total = (long)job.nx * job.ny * job.nt;
+    const long gid = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= total)
+        return;
+    const int ix = (int)(gid % job.nx);
+    const int iy = (int)((gid / job.nx) % job.ny);
+    const int it = (int)(gid / ((long)job.nx * job.ny));
+    const double px = job.px[ix], py = job.py[iy];
+    const double* rc = job.r_cos + (size_t)it * job.n_points;
+    const double* rs = job.r_sin + (size_t)it * job.n_points;
+    double sum = 0.0;
+    uint32_t known = 0;
+    for (int i = 0; i < job.n_points; ++i) {
+        const int c = cell_index(px + rc[i], job.off_x, job.res);
+        const int r = cell_index(py + rs[i], job.off_y, job.res);
+        uint32_t v = 0;
+        if (r >= 0 && r < job.rows && c >= 0 && c < job.cols)
+            v = job.cells[(size_t)r * job.pitch + c];
+        sum += job.lut[v];
+        known += v != 0;
+    }
+    const double score = sum / (double)job.n_points;
+    const size_t p = ((size_t)iy * job.nx + ix) * job.nt + it;   /* dy, dx, dt loop order */
+    job.out_score[p] = score;
+    job.out_k[p] = known;
+    if ((int)known >= job.min_known && score > job.score_thr)
+        atomicMax(job.best_bits, (unsigned long long)__double_as_longlong(score) + 1ull);   /* 0 = none yet */
+}
+
+/* first pose, in loop order, that reaches the maximum (the strict `>` update) */
+__global__ __launch_bounds__(kBlock) void k_grid_pick(GridSearchJob job)
+{
+    const long total = (long)job.nx * job.ny * job.nt;
+    const long p = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= total)
+        return;
+    const unsigned long long best = *job.best_bits;
+    if (best == 0ull)
+        return;
+    if ((int)job.out_k[p] >= job.min_known &&
+        (unsigned long long)__double_as_longlong(job.out_score[p]) + 1ull == best)
+        atomicMin(job.best_index, (unsigned long long)p);
+}
+
 /* ------------------------------------------------------------------ batch */
 __global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
 {

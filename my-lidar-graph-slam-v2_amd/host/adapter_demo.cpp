@@ -4,8 +4,9 @@
  * reference-side ScanMatcher / LoopDetector subclass would.
  *
  * case file (little endian):
- *   int32 mode(0 csm, 1 bnb loop detector, 2 correlative loop detector), rows, cols, n,
- *         n_queries, param_i (L or H)
+ *   int32 mode(0 csm, 1 bnb loop detector, 2 correlative loop detector, 3 grid search),
+ *         rows, cols, n, n_queries, param_i (L or H)
+ *   (mode 3 only: double step[3] right after the 8 doubles below)
  *   double res, offX, offY, rangeX, rangeY, rangeT, scoreThr, knownThr
  *   double rel[3]; double init[3 * n_queries]; double angles[n]; double ranges[n]
  *   uint16 grid[rows * cols]
@@ -31,7 +32,8 @@ int main(int argc, char** argv)
         return 2;
     int32_t hdr[6];
     double prm[8], rel[3];
-    if (!rd(f, hdr, 6) || !rd(f, prm, 8) || !rd(f, rel, 3))
+    double step[3] = { 0.0, 0.0, 0.0 };
+    if (!rd(f, hdr, 6) || !rd(f, prm, 8) || (hdr[0] == 3 && !rd(f, step, 3)) || !rd(f, rel, 3))
         return 2;
     const int mode = hdr[0], rows = hdr[1], cols = hdr[2], n = hdr[3], nq = hdr[4], pi = hdr[5];
     std::vector<double> init(3 * nq), angles(n), ranges(n);
@@ -54,6 +56,19 @@ int main(int argc, char** argv)
     s.mNumOfScans = n;
     s.mRelativeSensorPose = { rel[0], rel[1], rel[2] };
 
+    if (mode == 3) {
+        auto m = ScanMatcherGridSearchHIP::Create("demo", prm[3], prm[4], prm[5], step[0], step[1], step[2]);
+        if (!m) {
+            std::printf("{\"error\": \"no device\"}\n");
+            return 3;
+        }
+        ScanMatchingQuery q { g, s, { init[0], init[1], init[2] } };
+        const ScanMatchingSummary r = m->OptimizePose(q, prm[6], prm[7]);
+        std::printf("{\"found\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\", \"win\": [%d, %d, %d]}\n",
+                    r.mPoseFound ? 1 : 0, r.mEstimatedPose.mX, r.mEstimatedPose.mY,
+                    r.mEstimatedPose.mTheta, r.mScoreValue, r.mWinSizeX, r.mWinSizeY, r.mWinSizeTheta);
+        return 0;
+    }
     if (mode == 0) {
         auto m = ScanMatcherCorrelativeHIP::Create("demo", pi, prm[3], prm[4], prm[5]);
         if (!m) {

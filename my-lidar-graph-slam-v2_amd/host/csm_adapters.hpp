@@ -7,6 +7,7 @@
  *   LoopDetectorBranchBoundHIP  <- LoopDetectorBranchBound (search part)
  *        inc/mapping/loop_detector_branch_bound.hpp:71-112, loop_detector.hpp:97-116
  *   LoopDetectorCorrelativeHIP  <- LoopDetectorCorrelative (search part)
+ *   ScanMatcherGridSearchHIP    <- ScanMatcherGridSearch
  *        inc/mapping/loop_detector_correlative.hpp, src/mapping/loop_detector_correlative.cpp:59-156
  *
  * The reference headers cannot be included in this image (Eigen3 / Boost are
@@ -227,6 +228,78 @@ private:
     const std::string mName;
     const int mLowResolution;
     const double mRangeX, mRangeY, mRangeTheta;
+    const CostCallback mCostFunc;
+    detail::CtxPtr mCtx;
+};
+
+/* ScanMatcherGridSearch (inc/mapping/scan_matcher_grid_search.hpp,
+ * src/mapping/scan_matcher_grid_search.cpp:69-190): the brute-force matcher of
+ * LoopDetectorGridSearch; the pixel-accurate score function is the device
+ * kernel, the cost / covariance hook stays with the caller. */
+class ScanMatcherGridSearchHIP final {
+public:
+    static std::unique_ptr<ScanMatcherGridSearchHIP> Create(
+        const std::string& scanMatcherName, double rangeX, double rangeY, double rangeTheta,
+        double stepX, double stepY, double stepTheta, CostCallback costFunc = nullptr,
+        int deviceId = 0)
+    {
+        if (!(stepX > 0.0) || !(stepY > 0.0) || !(stepTheta > 0.0))
+            return nullptr;
+        detail::CtxPtr ctx = detail::MakeContext(deviceId);
+        if (!ctx)
+            return nullptr;
+        return std::unique_ptr<ScanMatcherGridSearchHIP>(new ScanMatcherGridSearchHIP(
+            scanMatcherName, rangeX, rangeY, rangeTheta, stepX, stepY, stepTheta, costFunc,
+            std::move(ctx)));
+    }
+
+    const std::string& Name() const { return this->mName; }
+
+    /* scan_matcher_grid_search.cpp:69-81 */
+    ScanMatchingSummary OptimizePose(const ScanMatchingQuery& queryInfo)
+    {
+        return this->OptimizePose(queryInfo, 0.0, 0.0);
+    }
+
+    /* scan_matcher_grid_search.cpp:84-190 */
+    ScanMatchingSummary OptimizePose(const ScanMatchingQuery& q,
+                                     const double normalizedScoreThreshold,
+                                     const double knownRateThreshold)
+    {
+        csm_ctx* ctx = this->mCtx.get();
+        const GridMapView& g = q.mGridMap;
+        const bool temporary = g.mId == GridMapView::kInvalidId;
+        const std::uint64_t id = temporary ? (1ull << 62) : g.mId;
+        if (temporary || !csm_has_grid(ctx, id))
+            CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, id, g.mValues, g.mRows, g.mCols));
+        csm_geometry geom { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
+        const csm_scan scan = detail::ToScan(q.mScanData);
+        const csm_grid_search_params prm { this->mRangeX, this->mRangeY, this->mRangeTheta,
+                                           this->mStepX, this->mStepY, this->mStepTheta,
+                                           normalizedScoreThreshold, knownRateThreshold };
+        const double init[3] = { q.mMapLocalInitialPose.mX, q.mMapLocalInitialPose.mY,
+                                 q.mMapLocalInitialPose.mTheta };
+        csm_summary s {};
+        CSM_ASSERT_OK(ctx, csm_grid_search_match(ctx, id, &geom, &scan, init, &prm, &s));
+        if (temporary)
+            CSM_ASSERT_OK(ctx, csm_release_grid(ctx, id));
+        ScanMatchingSummary out;
+        detail::FillSummary(s, q.mMapLocalInitialPose, &out);
+        if (this->mCostFunc)
+            this->mCostFunc(q, out.mBestSensorPose, &out.mNormalizedCost, out.mEstimatedCovariance);
+        return out;
+    }
+
+private:
+    ScanMatcherGridSearchHIP(const std::string& name, double rangeX, double rangeY,
+                             double rangeTheta, double stepX, double stepY, double stepTheta,
+                             CostCallback costFunc, detail::CtxPtr ctx) :
+        mName(name), mRangeX(rangeX), mRangeY(rangeY), mRangeTheta(rangeTheta), mStepX(stepX),
+        mStepY(stepY), mStepTheta(stepTheta), mCostFunc(costFunc), mCtx(std::move(ctx)) { }
+
+    const std::string mName;
+    const double mRangeX, mRangeY, mRangeTheta;
+    const double mStepX, mStepY, mStepTheta;
     const CostCallback mCostFunc;
     detail::CtxPtr mCtx;
 };

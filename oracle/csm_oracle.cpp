@@ -12,7 +12,7 @@
  * (pose.hpp, sensor/sensor_data.hpp) and the value->probability formula
  * (grid_map_new/grid_values.hpp) DO compile from the reference's own files;
  * oracle/Makefile builds them into oracle/_ref/libref_geom.so and
- * tests/test_oracle_ref.py checks this restatement against them bit for bit.
+ * tests/test_cpu_oracle.py checks this restatement against them bit for bit.
  * Everything else is restated from the cited lines and cross-checked by an
  * independent second formulation (literal sequential sweep vs closed form).
  *
@@ -590,6 +590,69 @@ int orc_bnb_level_dump(const uint16_t* level, int rows, int cols,
                 dumpS[idx] = S;
                 dumpK[idx] = static_cast<uint16_t>(K);
             }
+    return 0;
+}
+
+/* ScanMatcherGridSearch::OptimizePose, 5-argument overload:
+ * src/.../mapping/scan_matcher_grid_search.cpp:84-142. Offsets are accumulated
+ * doubles (dy += sy ...), every pose is projected on its own, and a pose counts
+ * only if its own known rate passes. bestIdx = (ix, iy, it) of the winner in
+ * the three loops (or -1s), for comparison with the device's indices. */
+struct OrcGridParams {
+    double rangeX, rangeY, rangeT;
+    double stepX, stepY, stepT;
+    double scoreThr, knownThr;
+};
+
+int orc_grid_search(const uint16_t* grid, int rows, int cols, const double* geom,
+                    const double* angles, const double* ranges, int n, const double* rel,
+                    const double* init, const OrcGridParams* p, OrcResult* out, int* bestIdx,
+                    long long* numEvaluations)
+{
+    Grid g { grid, rows, cols, geom[0], geom[1], geom[2] };
+    OrcScan s { angles, ranges, n, { rel[0], rel[1], rel[2] } };
+    const double* lut = shared_lut();
+    std::memset(out, 0, sizeof(*out));
+    orc_compound(init, s.rel, out->sensorPose);
+    const double rx = p->rangeX / 2.0, ry = p->rangeY / 2.0, rt = p->rangeT / 2.0;
+    const double sx = p->stepX, sy = p->stepY, st = p->stepT;
+    double scoreMax = p->scoreThr;
+    double best[3] = { out->sensorPose[0], out->sensorPose[1], out->sensorPose[2] };
+    bestIdx[0] = bestIdx[1] = bestIdx[2] = -1;
+    long long evals = 0;
+    int iy = 0;
+    for (double dy = -ry; dy <= ry; dy += sy, ++iy) {
+        int ix = 0;
+        for (double dx = -rx; dx <= rx; dx += sx, ++ix) {
+            int it = 0;
+            for (double dt = -rt; dt <= rt; dt += st, ++it) {
+                const double pose[3] = { out->sensorPose[0] + dx, out->sensorPose[1] + dy,
+                                         out->sensorPose[2] + dt };
+                const ScoreSummary sc = score_pixel_accurate(g, lut, s, pose);
+                ++evals;
+                if (sc.normalized > scoreMax && sc.knownRate > p->knownThr) {
+                    scoreMax = sc.normalized;
+                    best[0] = pose[0];
+                    best[1] = pose[1];
+                    best[2] = pose[2];
+                    bestIdx[0] = ix;
+                    bestIdx[1] = iy;
+                    bestIdx[2] = it;
+                }
+            }
+        }
+    }
+    out->found = scoreMax > p->scoreThr;
+    out->scoreMax = scoreMax;
+    out->stepX = sx;
+    out->stepY = sy;
+    out->stepT = st;
+    for (int k = 0; k < 3; ++k)
+        out->bestSensorPose[k] = best[k];
+    orc_move_backward(out->bestSensorPose, s.rel, out->estimatedPose);
+    out->fineEvaluated = evals;
+    if (numEvaluations)
+        *numEvaluations = evals;
     return 0;
 }
 

@@ -30,6 +30,12 @@ class BnbParams(C.Structure):
                 ("nodeHeightMax", C.c_int), ("scoreThr", C.c_double), ("knownThr", C.c_double)]
 
 
+class GridParams(C.Structure):
+    _fields_ = [("rangeX", C.c_double), ("rangeY", C.c_double), ("rangeT", C.c_double),
+                ("stepX", C.c_double), ("stepY", C.c_double), ("stepT", C.c_double),
+                ("scoreThr", C.c_double), ("knownThr", C.c_double)]
+
+
 class Result(C.Structure):
     _fields_ = [("found", C.c_int), ("bestX", C.c_int), ("bestY", C.c_int), ("bestT", C.c_int),
                 ("winX", C.c_int), ("winY", C.c_int), ("winT", C.c_int),
@@ -221,3 +227,20 @@ def score_at(level_grid, geom, angles, ranges, pose):
     s = lib().orc_score_at(_p(lv), lv.shape[0], lv.shape[1], _p(_f64(geom)), _p(a), _p(r),
                            a.size, _p(_f64(pose)), C.byref(known))
     return s, known.value
+
+
+def grid_search(case, range_x, range_y, range_t, step_x, step_y, step_t, score_thr=0.0, known_thr=0.0):
+    """Literal ScanMatcherGridSearch::OptimizePose."""
+    g = np.ascontiguousarray(case["grid"], dtype=np.uint16)
+    a, r = _f64(case["angles"]), _f64(case["ranges"])
+    geom, rel, init = _f64(case["geom"]), _f64(case["rel_pose"]), _f64(case["init_pose"])
+    p = GridParams(range_x, range_y, range_t, step_x, step_y, step_t, score_thr, known_thr)
+    out = Result()
+    idx = (C.c_int * 3)()
+    evals = C.c_longlong(0)
+    lib().orc_grid_search(_p(g), g.shape[0], g.shape[1], _p(geom), _p(a), _p(r), a.size, _p(rel),
+                          _p(init), C.byref(p), C.byref(out), idx, C.byref(evals))
+    d = out.as_dict()
+    d["bestIdx"] = list(idx)
+    d["evaluations"] = evals.value
+    return d

@@ -18,12 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEMO = os.path.join(ROOT, "my-lidar-graph-slam-v2_amd", "host", "adapter_demo")
 
 
-def _write_case(path, mode, case, inits, param_i, ranges3, thr):
+def _write_case(path, mode, case, inits, param_i, ranges3, thr, steps=None):
     g = np.ascontiguousarray(case["grid"], np.uint16)
     n = len(case["angles"])
     with open(path, "wb") as f:
         f.write(struct.pack("<6i", mode, g.shape[0], g.shape[1], n, len(inits), param_i))
         f.write(struct.pack("<8d", *case["geom"], *ranges3, *thr))
+        if steps is not None:
+            f.write(struct.pack("<3d", *steps))
         f.write(struct.pack("<3d", *case["rel_pose"]))
         f.write(np.asarray(inits, np.float64).tobytes())
         f.write(np.asarray(case["angles"], np.float64).tobytes())
@@ -92,3 +94,16 @@ def test_cpp_loop_detector_correlative_adapter(tmp_path, oracle):
     for g, w in zip(got, want):
         assert [float.fromhex(v) for v in g["pose"]] == w[1]
         assert float.fromhex(g["score"]) == w[2]
+
+
+def test_cpp_grid_search_adapter(tmp_path, oracle):
+    case = synth.csm_case(22, n_beams=180, rel_pose=(0.1, 0.02, -0.04))
+    p = str(tmp_path / "gs.bin")
+    window = (0.8, 0.6, 0.2)
+    steps = (0.05, 0.04, 0.01)
+    _write_case(p, 3, case, [case["init_pose"]], 0, window, (0.3, 0.5), steps)
+    got = _run(p)
+    want = oracle.grid_search(case, *window, *steps, 0.3, 0.5)
+    assert got["found"] == want["found"] == 1
+    assert [float.fromhex(v) for v in got["pose"]] == want["estimatedPose"]
+    assert float.fromhex(got["score"]) == want["scoreMax"]

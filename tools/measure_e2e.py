@@ -113,6 +113,19 @@ def main():
         algorithmic_TB=r["candidates"] * 2160 / 1e12, kernel_ms={k: v[0] for k, v in kt.items()},
         fine_algorithmic_GBs=r["candidates"] * 2160 / (kt["score_fine"][0] * 1e-3) / 1e9,
         flags=r["raw"]["flags"], found=r["pose_found"])
+    # brute-force matcher at the grid-search loop detector's default window
+    ctx.upload_grid(1, case["grid"])
+    gs = (2.5, 2.5, 0.5, 0.05, 0.05, 0.005, 0.3, 0.5)
+    r = ctx.grid_search_match(1, case["geom"], case["angles"], case["ranges"], case["rel_pose"],
+                              case["init_pose"], *gs)
+    ctx.reset_kernel_timing()
+    t0 = time.perf_counter()
+    r = ctx.grid_search_match(1, case["geom"], case["angles"], case["ranges"], case["rel_pose"],
+                              case["init_pose"], *gs)
+    dt = time.perf_counter() - t0
+    out["grid_search_default_window"] = dict(
+        ms_per_call=dt * 1e3, candidates=r["candidates"], poses_per_s=r["candidates"] / dt,
+        kernel_ms=ctx.kernel_time("grid_search")[0], found=r["pose_found"])
     print(json.dumps(out, indent=1))
 
 
