@@ -119,3 +119,30 @@ def csm_case(seed, rows=400, cols=400, res=0.05, n_beams=360, fov=2 * math.pi,
     init = (truth[0] + init_error[0], truth[1] + init_error[1], truth[2] + init_error[2])
     return dict(grid=grid, geom=geom, angles=angles, ranges=ranges, truth=truth,
                 init_pose=init, rel_pose=rel_pose, segs=segs)
+
+
+def map_case(seed, n_scans=10, n_beams=1080, fov=1.5 * math.pi, max_range=8.0, res=0.05,
+             step=0.12, rel_pose=(0.0, 0.0, 0.0), noise=0.0, **room_kw):
+    """Input of a map build (GridMapBuilder::ConstructMapFromScans): a short
+    trajectory of scan nodes inside a synthetic room. Returns dict(nodes,
+    map_pose, shape) with shape = the freshly constructed 1 m x 1 m map the
+    reference starts from (grid_map_builder.cpp:80)."""
+    _, _, segs = make_room(seed, 400, 400, res, **room_kw)
+    rng = np.random.RandomState(seed + 4242)
+    x, y, th = 0.3 * (rng.rand() - 0.5), 0.3 * (rng.rand() - 0.5), rng.rand() * 2 * math.pi
+    nodes = []
+    for k in range(n_scans):
+        pose = (x, y, th)
+        sensor = (x + math.cos(th) * rel_pose[0] - math.sin(th) * rel_pose[1],
+                  y + math.sin(th) * rel_pose[0] + math.cos(th) * rel_pose[1], th + rel_pose[2])
+        angles, ranges = cast_scan(segs, sensor, n_beams, fov, max_range, noise=noise, seed=seed + k)
+        nodes.append(dict(pose=pose, angles=angles, ranges=ranges, rel_pose=rel_pose,
+                          min_range=0.05, max_range=max_range))
+        th += 0.15 * (rng.rand() - 0.5)
+        x += step * math.cos(th)
+        y += step * math.sin(th)
+    block = 16
+    n = int(math.ceil(1.0 / res))
+    n = (n + block - 1) // block * block
+    shape = dict(res=res, off_x=0.0, off_y=0.0, rows=n, cols=n, log2_block=4)
+    return dict(nodes=nodes, map_pose=nodes[0]["pose"], shape=shape, segs=segs)

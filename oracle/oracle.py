@@ -244,3 +244,73 @@ def grid_search(case, range_x, range_y, range_t, step_x, step_y, step_t, score_t
     d["bestIdx"] = list(idx)
     d["evaluations"] = evals.value
     return d
+
+
+# ---- map building (oracle/map_oracle.cpp) ----
+
+class MapShape(C.Structure):
+    _fields_ = [("res", C.c_double), ("offX", C.c_double), ("offY", C.c_double),
+                ("rows", C.c_int), ("cols", C.c_int), ("log2Block", C.c_int)]
+
+
+class ScanNode(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("angles", C.c_void_p), ("ranges", C.c_void_p),
+                ("n", C.c_int), ("rel", C.c_double * 3), ("minRange", C.c_double),
+                ("maxRange", C.c_double)]
+
+
+class BuilderParams(C.Structure):
+    _fields_ = [("usableMin", C.c_double), ("usableMax", C.c_double), ("probHit", C.c_double),
+                ("probMiss", C.c_double), ("subpixel", C.c_int)]
+
+
+def _nodes(nodes):
+    keep = []
+    arr = (ScanNode * len(nodes))()
+    for i, nd in enumerate(nodes):
+        a, r = _f64(nd["angles"]), _f64(nd["ranges"])
+        keep += [a, r]
+        arr[i].pose[:] = list(nd["pose"])
+        arr[i].angles = a.ctypes.data
+        arr[i].ranges = r.ctypes.data
+        arr[i].n = a.size
+        arr[i].rel[:] = list(nd.get("rel_pose", (0.0, 0.0, 0.0)))
+        arr[i].minRange = nd.get("min_range", 0.0)
+        arr[i].maxRange = nd.get("max_range", 1e9)
+    return arr, keep
+
+
+def construct_map(shape, map_pose, nodes, usable_min=0.01, usable_max=20.0, prob_hit=0.62,
+                  prob_miss=0.46, subpixel=100):
+    """Literal GridMapBuilder::ConstructMapFromScans on a dense array. shape =
+    dict(res, off_x, off_y, rows, cols, log2_block) of the map BEFORE the call.
+    Returns (new shape dict, grid, stats dict)."""
+    sh = MapShape(shape["res"], shape["off_x"], shape["off_y"], shape["rows"], shape["cols"],
+                  shape["log2_block"])
+    arr, keep = _nodes(nodes)
+    prm = BuilderParams(usable_min, usable_max, prob_hit, prob_miss, subpixel)
+    mp = _f64(map_pose)
+    rc = lib().orc_map_resize(C.byref(sh), _p(mp), arr, len(nodes), C.byref(prm))
+    if rc:
+        raise ValueError("orc_map_resize failed: %d" % rc)
+    grid = np.zeros((sh.rows, sh.cols), np.uint16)
+    stats = (C.c_longlong * 4)()
+    rc = lib().orc_map_integrate(C.byref(sh), _p(mp), arr, len(nodes), C.byref(prm), _p(grid), stats)
+    if rc:
+        raise ValueError("orc_map_integrate failed: %d" % rc)
+    new_shape = dict(res=sh.res, off_x=sh.offX, off_y=sh.offY, rows=sh.rows, cols=sh.cols,
+                     log2_block=sh.log2Block)
+    return new_shape, grid, dict(rays=stats[0], updates=stats[1], oob_reads=stats[2],
+                                 end_missing=stats[3])
+
+
+def ray_cells(sx, sy, ex, ey, scale=100, cap=1 << 16):
+    out = np.zeros(2 * cap, np.int32)
+    n = lib().orc_ray_cells(sx, sy, ex, ey, scale, _p(out), cap)
+    return [tuple(out[2 * i:2 * i + 2]) for i in range(min(n, cap))]
+
+
+def bayes_update(value, prob):
+    lib().orc_bayes_update.restype = C.c_uint
+    lib().orc_bayes_update.argtypes = [C.c_uint, C.c_double]
+    return lib().orc_bayes_update(value, prob)
