@@ -285,6 +285,56 @@ int  csm_grid_search_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* ge
                            const csm_scan* scan, const double initial_pose[3],
                            const csm_grid_search_params* params, csm_summary* out);
 
+/* ---- map building: the producer of the matcher's input ---- */
+
+/* One scan node of the window [scanNodeIdMin, scanNodeIdMax]
+ * (ScanNode, inc/mapping/pose_graph.hpp; ScanData, inc/sensor/sensor_data.hpp) */
+typedef struct {
+    double   global_pose[3];      /* ScanNode::mGlobalPose */
+    csm_scan scan;
+    double   min_range, max_range;   /* ScanData::MinRange / MaxRange */
+} csm_scan_node;
+
+/* GridMapBuilder constructor arguments that the map update reads
+ * (src/mapping/grid_map_builder.cpp:68-99) + its SubpixelScale constant
+ * (inc/mapping/grid_map_builder.hpp:294) */
+typedef struct {
+    double  usable_range_min, usable_range_max;
+    double  prob_hit, prob_miss;
+    int32_t subpixel_scale;
+} csm_map_builder_params;
+
+/* GridMapGeometry + block size of a GridMap (inc/grid_map_new/grid_map.hpp).
+ * In: the map BEFORE the call (Resize works in its frame). Out: after it. */
+typedef struct {
+    double  resolution, offset_x, offset_y;
+    int32_t rows, cols;
+    int32_t log2_block_size;
+} csm_map_shape;
+
+typedef struct {
+    int64_t rays;               /* usable beams integrated */
+    int64_t cell_updates;       /* hit + miss updates applied */
+    int64_t saturated_reads;    /* updates of a cell already at 65535: the reference's odds table
+                                   (grid_values.cpp:74-77) has no such entry (undefined behaviour
+                                   there); this library extends the table's formula */
+    int32_t first_known_row, first_known_col;
+    double  host_us;            /* hit points (glibc sin/cos) + resize */
+    double  device_us;          /* upload + kernels */
+} csm_map_build_info;
+
+/* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:561-695)
+ * = UpdateLatestMap's work (:497-527): bounding box of the sensor positions and
+ * usable hit points, GridMap::Resize + ResetValues, then a sub-pixel ray cast
+ * per beam (BresenhamScaled, src/bresenham.cpp:58-237) with binary-Bayes miss /
+ * hit updates in beam order. The finished map becomes (or replaces) the
+ * resident grid `map_id`, ready for the matchers; csm_download_level(level 0)
+ * returns it as CopyValues would. `info` may be null. */
+int  csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
+                                  const double global_map_pose[3], const csm_scan_node* nodes,
+                                  int32_t n_nodes, const csm_map_builder_params* params,
+                                  csm_map_build_info* info);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* enable = 1: every kernel launch is bracketed by HIP events on the ctx
  * stream; enable = 2: only the dominant (fine-level) scoring kernel, to keep

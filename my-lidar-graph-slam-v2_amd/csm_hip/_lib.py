@@ -55,6 +55,27 @@ class BnbParams(C.Structure):
                 ("known_rate_threshold", C.c_double)]
 
 
+class ScanNode(C.Structure):
+    _fields_ = [("global_pose", C.c_double * 3), ("scan", Scan), ("min_range", C.c_double),
+                ("max_range", C.c_double)]
+
+
+class MapBuilderParams(C.Structure):
+    _fields_ = [("usable_range_min", C.c_double), ("usable_range_max", C.c_double),
+                ("prob_hit", C.c_double), ("prob_miss", C.c_double), ("subpixel_scale", C.c_int32)]
+
+
+class MapShape(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("offset_x", C.c_double), ("offset_y", C.c_double),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("log2_block_size", C.c_int32)]
+
+
+class MapBuildInfo(C.Structure):
+    _fields_ = [("rays", C.c_int64), ("cell_updates", C.c_int64), ("saturated_reads", C.c_int64),
+                ("first_known_row", C.c_int32), ("first_known_col", C.c_int32),
+                ("host_us", C.c_double), ("device_us", C.c_double)]
+
+
 class GridSearchParams(C.Structure):
     _fields_ = [("range_x", C.c_double), ("range_y", C.c_double), ("range_theta", C.c_double),
                 ("step_x", C.c_double), ("step_y", C.c_double), ("step_theta", C.c_double),
@@ -135,6 +156,8 @@ SIGNATURES = {
                                               _P(CorrelativeParams), _P(Summary)]),
     "csm_grid_search_match": (C.c_int, [_ctx, C.c_uint64, _P(Geometry), _P(Scan), C.c_void_p,
                                         _P(GridSearchParams), _P(Summary)]),
+    "csm_construct_map_from_scans": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
+                                               C.c_int32, _P(MapBuilderParams), _P(MapBuildInfo)]),
     "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),
     "csm_kernel_time": (C.c_int, [_ctx, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "csm_reset_kernel_timing": (C.c_int, [_ctx]),

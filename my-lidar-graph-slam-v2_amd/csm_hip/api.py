@@ -220,6 +220,39 @@ class Context:
                                                    _ptr(init), C.byref(p), C.byref(out)))
         return summary_to_dict(out)
 
+    def construct_map_from_scans(self, map_id, shape, map_pose, nodes, usable_range_min=0.01,
+                                 usable_range_max=20.0, prob_hit=0.62, prob_miss=0.46,
+                                 subpixel_scale=100):
+        """GridMapBuilder::ConstructMapFromScans
+        (src/my_lidar_graph_slam/mapping/grid_map_builder.cpp:561-695) on the
+        device; the result becomes the resident grid `map_id`. shape = dict(res,
+        off_x, off_y, rows, cols, log2_block) of the map before the call; nodes =
+        dicts(pose, angles, ranges, rel_pose, min_range, max_range). Returns
+        (new shape dict, info dict); defaults as launcher_settings_default.json:183-186."""
+        sh = L.MapShape(shape["res"], shape["off_x"], shape["off_y"], shape["rows"], shape["cols"],
+                        shape["log2_block"])
+        arr = (L.ScanNode * len(nodes))()
+        keep = []
+        for i, nd in enumerate(nodes):
+            a_, r_ = _f64(nd["angles"]), _f64(nd["ranges"])
+            keep += [a_, r_]
+            arr[i].global_pose[:] = list(nd["pose"])
+            arr[i].scan.angles = a_.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].scan.ranges = r_.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].scan.n_points = a_.size
+            arr[i].scan.relative_sensor_pose[:] = list(nd.get("rel_pose", (0.0, 0.0, 0.0)))
+            arr[i].min_range = nd.get("min_range", 0.0)
+            arr[i].max_range = nd.get("max_range", 1e9)
+        prm = L.MapBuilderParams(usable_range_min, usable_range_max, prob_hit, prob_miss, subpixel_scale)
+        info = L.MapBuildInfo()
+        mp = _f64(map_pose)
+        self._check(self.lib.csm_construct_map_from_scans(self._ctx, map_id, C.byref(sh), _ptr(mp), arr,
+                                                          len(nodes), C.byref(prm), C.byref(info)))
+        self.shapes[map_id] = (sh.rows, sh.cols)
+        new_shape = dict(res=sh.resolution, off_x=sh.offset_x, off_y=sh.offset_y, rows=sh.rows,
+                         cols=sh.cols, log2_block=sh.log2_block_size)
+        return new_shape, {name: getattr(info, name) for name, _ in L.MapBuildInfo._fields_}
+
     def grid_search_match(self, map_id, geom, angles, ranges, rel_pose, init_pose,
                           range_x, range_y, range_theta, step_x, step_y, step_theta,
                           score_threshold=0.0, known_rate_threshold=0.0):

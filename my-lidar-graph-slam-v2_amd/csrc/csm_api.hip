@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <limits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -37,6 +38,8 @@ struct Level {
     int       win = 1;
     uint16_t* cells = nullptr;   /* pitched rows*pitch */
     bool      owned = false;
+    bool      stale = false;     /* derived from a base that was rebuilt since */
+    size_t    cap = 0;           /* bytes allocated (owned levels) */
 };
 
 struct DeviceGrid {
@@ -68,6 +71,9 @@ struct csm_ctx {
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
+    /* map building */
+    DevBuf m_rays, m_recs, m_cell, m_lists, m_cnt, m_lut;
+    double m_lut_hit = -1.0, m_lut_miss = -1.0;   /* probabilities the update tables were built for */
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -487,7 +493,10 @@ void free_levels(DeviceGrid& g, bool keep_base)
     g.levels.resize(keep_base && !g.levels.empty() ? 1 : 0);
 }
 
-int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out)
+/* `reuse`: a buffer of at least rows*pitch*2 bytes to build into (its capacity
+ * in *reuse_cap), or null to allocate one */
+int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out, uint16_t* reuse = nullptr,
+                size_t reuse_cap = 0)
 {
     if (win < 1 || win > g.rows || win > g.cols)
         return fail(ctx, CSM_EINVAL, "box-max window %d does not fit %dx%d", win, g.rows, g.cols);
@@ -495,9 +504,13 @@ int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out)
     int rc = ensure(ctx, ctx->scratch, bytes);
     if (rc)
         return rc;
-    uint16_t* dst = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&dst), bytes) != hipSuccess)
-        return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    uint16_t* dst = reuse;
+    size_t cap = reuse_cap;
+    if (!dst) {
+        if (hipMalloc(reinterpret_cast<void**>(&dst), bytes) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+        cap = bytes;
+    }
     const dim3 grid(ceil_div(g.pitch, kBlock), g.rows);
     {
         ScopedTimer tm(ctx, "boxmax");
@@ -508,12 +521,15 @@ int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out)
                            g.pitch, win);
     }
     if (hipGetLastError() != hipSuccess) {
-        (void)hipFree(dst);
+        if (!reuse)
+            (void)hipFree(dst);
         return fail(ctx, CSM_EIO, "box-max launch failed");
     }
     out->win = win;
     out->cells = dst;
     out->owned = true;
+    out->stale = false;
+    out->cap = cap;
     return CSM_OK;
 }
 
@@ -522,6 +538,24 @@ int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index)
 {
     for (size_t i = 0; i < g.levels.size(); ++i)
         if (g.levels[i].win == win) {
+            Level& have = g.levels[i];
+            if (have.stale) {
+                /* the base was rebuilt (csm_construct_map_from_scans): redo the box
+                 * maximum, into the old buffer when it is large enough */
+                const size_t bytes = (size_t)g.rows * g.pitch * 2;
+                const bool fits = have.owned && have.cap >= bytes;
+                if (have.owned && !fits) {
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    (void)hipFree(have.cells);
+                    have.cells = nullptr;
+                    have.cap = 0;
+                }
+                Level fresh;
+                int rc = build_level(ctx, g, win, &fresh, fits ? have.cells : nullptr, have.cap);
+                if (rc)
+                    return rc;
+                have = fresh;
+            }
             *index = (int)i;
             return CSM_OK;
         }
@@ -546,6 +580,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
 {
     if (w->coarse_level < 0 || w->coarse_level >= (int)g.levels.size())
         return fail(ctx, CSM_ENOENT, "coarse level %d not built", w->coarse_level);
+    if (g.levels[w->coarse_level].stale)
+        return fail(ctx, CSM_ENOENT, "coarse level %d is stale: the map was rebuilt", w->coarse_level);
     if (g.levels[w->coarse_level].win != p.L)
         return fail(ctx, CSM_EINVAL, "level %d holds box-max(%d), window asks L=%d",
                     w->coarse_level, g.levels[w->coarse_level].win, p.L);
@@ -957,7 +993,8 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
-                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc };
+                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc,
+                       &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
     for (DevBuf* b : bufs)
         if (b->p)
             (void)hipFree(b->p);
@@ -1028,6 +1065,7 @@ int csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense, int32_
     }
     base.win = 1;
     base.owned = true;
+    base.cap = bytes;
     g.levels.push_back(base);
     HIP_TRY(ctx, hipMemsetAsync(base.cells, 0, bytes, ctx->stream));
     HIP_TRY(ctx, hipMemcpy2DAsync(base.cells, (size_t)g.pitch * 2, dense, (size_t)cols * 2,
@@ -1094,7 +1132,7 @@ int csm_download_level(csm_ctx* ctx, uint64_t map_id, int32_t level, uint16_t* o
     if (!ctx || !out)
         return fail(ctx, CSM_EINVAL, "csm_download_level: bad arguments");
     DeviceGrid* g = find_grid(ctx, map_id);
-    if (!g || level < 0 || level >= (int)g->levels.size())
+    if (!g || level < 0 || level >= (int)g->levels.size() || g->levels[level].stale)
         return fail(ctx, CSM_ENOENT, "map %llu level %d not resident",
                     (unsigned long long)map_id, level);
     HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)g->cols * 2, g->levels[level].cells,
@@ -2100,6 +2138,276 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
     for (int i = 0; i < n_queries; ++i) {
         out[i].input_setup_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / n_queries;
         out[i].optimization_us = std::chrono::duration<double, std::micro>(t2 - t1).count() / n_queries;
+    }
+    return CSM_OK;
+}
+
+/* ---- map building ---- */
+
+namespace {
+
+/* GridBinaryBayes's conversions (src/grid_map_new/grid_binary_bayes.cpp:345-383,
+ * inc/grid_map_new/grid_values.hpp:11-46) with its constants: values 1..65535
+ * stand for probabilities 0.001..0.999, 0 = unknown. */
+const double kBayesProbMin = 1e-3;
+const double kBayesProbMax = 1.0 - 1e-3;
+
+double bayes_probability_to_odds(double prob)
+{
+    if (prob == 0.0)
+        return 1.0;
+    if (prob < kBayesProbMin)
+        return kBayesProbMin / (1.0 - kBayesProbMin);
+    if (prob > kBayesProbMax)
+        return kBayesProbMax / (1.0 - kBayesProbMax);
+    return prob / (1.0 - prob);
+}
+
+uint16_t bayes_value_after(uint32_t value, double odds)
+{
+    /* GridBinaryBayes::UpdateOddsUnchecked (grid_binary_bayes.cpp:302-321) */
+    double now = odds;
+    if (value != 0) {
+        const double p = kBayesProbMin + (kBayesProbMax - kBayesProbMin) *
+                         static_cast<double>(static_cast<int>(value) - 1) / 65534.0;
+        now = (p / (1.0 - p)) * odds;
+    }
+    double prob = 0.0;
+    if (!(now < 0.0))
+        prob = std::min(std::max(now / (1.0 + now), kBayesProbMin), kBayesProbMax);
+    if (prob == 0.0)
+        return 0;
+    if (prob < kBayesProbMin)
+        return 1;
+    if (prob > kBayesProbMax)
+        return 65535;
+    return static_cast<uint16_t>(1 + (prob - kBayesProbMin) * 65534.0 / (kBayesProbMax - kBayesProbMin));
+}
+
+/* GridMap<T>::IndexToBlock (src/grid_map_new/grid_map.cpp:804-814): a negative
+ * index lands one block further out than a floor would put it */
+int map_index_to_block(int idx, int log2_block)
+{
+    return idx >= 0 ? (idx >> log2_block) : ((idx >> log2_block) - 1);
+}
+
+} /* namespace */
+
+/* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:561-695) */
+int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
+                                 const double global_map_pose[3], const csm_scan_node* nodes,
+                                 int32_t n_nodes, const csm_map_builder_params* prm,
+                                 csm_map_build_info* info)
+{
+    if (!ctx || !shape || !global_map_pose || !nodes || n_nodes < 1 || !prm ||
+        !(shape->resolution > 0.0) || shape->log2_block_size < 0 || shape->log2_block_size > 12 ||
+        prm->subpixel_scale < 1 || prm->subpixel_scale > 1024)
+        return fail(ctx, CSM_EINVAL, "csm_construct_map_from_scans: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int scale = prm->subpixel_scale;
+    const double res = shape->resolution;
+
+    /* grid_map_builder.cpp:583-638: sensor poses, usable hit points, bounding box */
+    double min_x = std::numeric_limits<double>::max(), min_y = min_x;
+    double max_x = std::numeric_limits<double>::min(), max_y = max_x;   /* as the reference: smallest positive */
+    struct NodeSensor { double x, y; };
+    std::vector<NodeSensor> sensors(n_nodes);
+    std::vector<MapRay> rays;
+    std::vector<int32_t> ray_node;
+    for (int k = 0; k < n_nodes; ++k) {
+        const csm_scan_node& nd = nodes[k];
+        if (!nd.scan.angles || !nd.scan.ranges || nd.scan.n_points < 0)
+            return fail(ctx, CSM_EINVAL, "scan node %d has no scan", k);
+        double global_sensor[3], local_sensor[3];
+        csm_host_compound(nd.global_pose, nd.scan.relative_sensor_pose, global_sensor);
+        csm_host_inverse_compound(global_map_pose, global_sensor, local_sensor);
+        sensors[k] = { local_sensor[0], local_sensor[1] };
+        min_x = std::min(min_x, local_sensor[0]);
+        min_y = std::min(min_y, local_sensor[1]);
+        max_x = std::max(max_x, local_sensor[0]);
+        max_y = std::max(max_y, local_sensor[1]);
+        const double min_range = std::max(prm->usable_range_min, nd.min_range);
+        const double max_range = std::min(prm->usable_range_max, nd.max_range);
+        for (int i = 0; i < nd.scan.n_points; ++i) {
+            const double r = nd.scan.ranges[i];
+            if (r >= max_range || r <= min_range)
+                continue;
+            /* ScanData::HitPoint (inc/sensor/sensor_data.hpp:189-203) */
+            const double c = std::cos(local_sensor[2] + nd.scan.angles[i]);
+            const double s = std::sin(local_sensor[2] + nd.scan.angles[i]);
+            MapRay ray;
+            ray.hx = local_sensor[0] + r * c;
+            ray.hy = local_sensor[1] + r * s;
+            ray.sx = ray.sy = 0;
+            rays.push_back(ray);
+            ray_node.push_back(k);
+            min_x = std::min(min_x, ray.hx);
+            min_y = std::min(min_y, ray.hy);
+            max_x = std::max(max_x, ray.hx);
+            max_y = std::max(max_y, ray.hy);
+        }
+    }
+    if (!(min_x < max_x) || !(min_y < max_y))
+        return fail(ctx, CSM_EINVAL, "empty bounding box (the reference asserts)");
+
+    /* GridMap::Resize, both overloads (grid_map.cpp:841-913), on the CURRENT geometry */
+    auto to_index = [res](double p, double off) { return static_cast<int>(std::floor((p - off) / res)); };
+    const int lb = shape->log2_block_size, block = 1 << lb;
+    const int i_min_x = to_index(min_x - res, shape->offset_x), i_min_y = to_index(min_y - res, shape->offset_y);
+    const int i_max_x = to_index(max_x + res, shape->offset_x) + 1, i_max_y = to_index(max_y + res, shape->offset_y) + 1;
+    const int b_min_x = map_index_to_block(i_min_x, lb), b_min_y = map_index_to_block(i_min_y, lb);
+    const int b_max_x = map_index_to_block(i_max_x + block - 1, lb);
+    const int b_max_y = map_index_to_block(i_max_y + block - 1, lb);
+    const long long rows_ll = (long long)(b_max_y - b_min_y) << lb, cols_ll = (long long)(b_max_x - b_min_x) << lb;
+    if (rows_ll < 1 || cols_ll < 1 || rows_ll * cols_ll > (1ll << 28))
+        return fail(ctx, CSM_EINVAL, "resized map %lld x %lld is out of range", rows_ll, cols_ll);
+    const int rows = (int)rows_ll, cols = (int)cols_ll;
+    /* GridMapGeometry::Resize (grid_map_geometry.cpp:61-72) */
+    const double off_x = shape->offset_x + res * (b_min_x << lb);
+    const double off_y = shape->offset_y + res * (b_min_y << lb);
+    const double scaled_res = res / scale;                  /* ScaledGeometry, :46-58 */
+    for (size_t i = 0; i < rays.size(); ++i) {
+        const NodeSensor& sn = sensors[ray_node[i]];
+        rays[i].sx = static_cast<int>(std::floor((sn.x - off_x) / scaled_res));
+        rays[i].sy = static_cast<int>(std::floor((sn.y - off_y) / scaled_res));
+    }
+    const int n_rays = (int)rays.size();
+    const size_t n_cells = (size_t)rows * cols;
+
+    /* the two value -> value tables of the cell update */
+    int rc = 0;
+    if ((rc = ensure(ctx, ctx->m_lut, 2 * 65536 * sizeof(uint16_t)))) return rc;
+    uint16_t* d_lut = reinterpret_cast<uint16_t*>(ctx->m_lut.p);
+    if (ctx->m_lut_hit != prm->prob_hit || ctx->m_lut_miss != prm->prob_miss) {
+        std::vector<uint16_t> tab(2 * 65536);
+        const double odds_hit = bayes_probability_to_odds(prm->prob_hit);     /* grid_map_builder.cpp:95-96 */
+        const double odds_miss = bayes_probability_to_odds(prm->prob_miss);
+        for (uint32_t v = 0; v < 65536; ++v) {
+            tab[v] = bayes_value_after(v, odds_hit);
+            tab[65536 + v] = bayes_value_after(v, odds_miss);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(d_lut, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->m_lut_hit = prm->prob_hit;
+        ctx->m_lut_miss = prm->prob_miss;
+    }
+
+    /* the destination grid: keep the old allocation when it is large enough */
+    DeviceGrid& g = ctx->grids[map_id];
+    const int pitch = (cols + 7) & ~7;
+    const size_t bytes = (size_t)rows * pitch * 2;
+    if (g.levels.empty() || !g.levels[0].owned || g.levels[0].cap < bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        free_levels(g, false);
+        Level base;
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc(reinterpret_cast<void**>(&base.cells), want) != hipSuccess) {
+            ctx->grids.erase(map_id);
+            return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", want);
+        }
+        base.win = 1;
+        base.owned = true;
+        base.cap = want;
+        g.levels.push_back(base);
+    }
+    for (size_t i = 1; i < g.levels.size(); ++i) {
+        if (g.levels[i].owned)
+            g.levels[i].stale = true;
+        else
+            g.levels[i].cells = g.levels[0].cells;     /* an alias of the base (window 1) */
+    }
+    g.rows = rows;
+    g.cols = cols;
+    g.pitch = pitch;
+    g.known_r0 = 0;
+    g.known_c0 = 0;
+
+    if ((rc = ensure(ctx, ctx->m_rays, (size_t)std::max(n_rays, 1) * sizeof(MapRay)))) return rc;
+    if ((rc = ensure(ctx, ctx->m_recs, (size_t)std::max(n_rays, 1) * sizeof(MapRayRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->m_cell, 3 * n_cells * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->m_lists, (4 * (size_t)n_rays + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->m_cnt, kMapCounters * sizeof(unsigned long long)))) return rc;
+    MapJob mj;
+    std::memset(&mj, 0, sizeof(mj));
+    mj.rays = reinterpret_cast<const MapRay*>(ctx->m_rays.p);
+    mj.recs = reinterpret_cast<MapRayRec*>(ctx->m_recs.p);
+    mj.n_rays = n_rays;
+    mj.off_x = off_x;
+    mj.off_y = off_y;
+    mj.res = res;
+    mj.scaled_res = scaled_res;
+    mj.scale = scale;
+    mj.rows = rows;
+    mj.cols = cols;
+    mj.pitch = pitch;
+    mj.n_hit = reinterpret_cast<uint32_t*>(ctx->m_cell.p);
+    mj.n_miss = mj.n_hit + n_cells;
+    mj.seg = mj.n_miss + n_cells;
+    mj.lists = reinterpret_cast<uint32_t*>(ctx->m_lists.p);
+    mj.counters = reinterpret_cast<unsigned long long*>(ctx->m_cnt.p);
+    mj.lut_hit = d_lut;
+    mj.lut_miss = d_lut + 65536;
+    mj.cells = g.levels[0].cells;
+    unsigned long long counters[kMapCounters] = { 0, 0, 0, 0, ~0ull, ~0ull };
+    const auto t1 = std::chrono::steady_clock::now();
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (info) {
+        HIP_TRY(ctx, hipEventCreate(&ev_a));
+        HIP_TRY(ctx, hipEventCreate(&ev_b));
+        HIP_TRY(ctx, hipEventRecord(ev_a, ctx->stream));
+    }
+    if (n_rays)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->m_rays.p, rays.data(), (size_t)n_rays * sizeof(MapRay),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mj.counters, counters, sizeof(counters), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(mj.n_hit, 0, 2 * n_cells * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(mj.lists, 0, (4 * (size_t)n_rays + 4) * sizeof(uint32_t), ctx->stream));
+    {
+        ScopedTimer tm(ctx, "map_build");
+        const unsigned ray_blocks = (unsigned)ceil_div(std::max(n_rays, 1), 256);
+        const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
+        if (n_rays) {
+            hipLaunchKernelGGL(k_map_hits, dim3(ray_blocks), dim3(256), 0, ctx->stream, mj);
+            hipLaunchKernelGGL(k_map_alloc, dim3(cell_blocks), dim3(256), 0, ctx->stream, mj);
+            hipLaunchKernelGGL(k_map_fill_hits, dim3(ray_blocks), dim3(256), 0, ctx->stream, mj);
+            hipLaunchKernelGGL(k_map_rank_hits, dim3(ray_blocks), dim3(256), 0, ctx->stream, mj);
+            hipLaunchKernelGGL(k_map_walk, dim3((unsigned)ceil_div(n_rays, 4)), dim3(256), 0, ctx->stream, mj);
+        }
+        hipLaunchKernelGGL(k_map_apply, dim3((unsigned)(((size_t)rows * pitch + 255) / 256)), dim3(256), 0,
+                           ctx->stream, mj);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (info)
+        HIP_TRY(ctx, hipEventRecord(ev_b, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(counters, mj.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float dev_ms = 0.f;
+    if (info) {
+        (void)hipEventElapsedTime(&dev_ms, ev_a, ev_b);
+        (void)hipEventDestroy(ev_a);
+        (void)hipEventDestroy(ev_b);
+    }
+    if (counters[kMapError]) {
+        free_levels(g, false);
+        ctx->grids.erase(map_id);
+        return fail(ctx, CSM_EINVAL, "a ray leaves the resized map (flags %llu): the reference asserts",
+                    counters[kMapError]);
+    }
+    g.known_r0 = counters[kMapKnownRow] == ~0ull ? rows : (int)counters[kMapKnownRow];
+    g.known_c0 = counters[kMapKnownCol] == ~0ull ? cols : (int)counters[kMapKnownCol];
+    shape->rows = rows;
+    shape->cols = cols;
+    shape->offset_x = off_x;
+    shape->offset_y = off_y;
+    if (info) {
+        info->rays = n_rays;
+        info->cell_updates = (int64_t)counters[kMapUpdates];
+        info->saturated_reads = (int64_t)counters[kMapSaturatedReads];
+        info->first_known_row = g.known_r0;
+        info->first_known_col = g.known_c0;
+        info->host_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        info->device_us = dev_ms * 1e3;
     }
     return CSM_OK;
 }

@@ -231,5 +231,37 @@ struct GridSearchJob {
     unsigned long long* best_index;  /* [1] first pose index reaching it */
 };
 
+/* Map building from scans (GridMapBuilder::ConstructMapFromScans). A ray is one
+ * usable beam of one scan node, numbered in the reference's update order. */
+struct MapRay {
+    double  hx, hy;            /* hit point, map-local (host, glibc) */
+    int32_t sx, sy;            /* sub-pixel index of its node's sensor position */
+};
+struct MapRayRec {
+    int32_t ex, ey;            /* sub-pixel index of the hit point */
+    int32_t hit_cell;          /* row * cols + col, or -1 if the ray was rejected */
+    int32_t slot;              /* arrival number among the hits of that cell */
+};
+enum MapCounter {
+    kMapCursor = 0, kMapError, kMapSaturatedReads, kMapUpdates, kMapKnownRow, kMapKnownCol,
+    kMapCounters
+};
+struct MapJob {
+    const MapRay* rays;
+    MapRayRec* recs;
+    int32_t n_rays;
+    double  off_x, off_y, res, scaled_res;
+    int32_t scale;
+    int32_t rows, cols, pitch;
+    uint32_t* n_hit;           /* [rows * cols] hits ending in the cell */
+    uint32_t* n_miss;          /* [rows * cols] misses of cells no ray ends in */
+    uint32_t* seg;             /* [rows * cols] start of the cell's block in `lists` */
+    uint32_t* lists;           /* per cell with n hits: arrival[n] sorted[n] misses_between[n + 1] */
+    unsigned long long* counters;   /* [kMapCounters] */
+    const uint16_t* lut_hit;   /* value -> value after one hit / miss update */
+    const uint16_t* lut_miss;
+    uint16_t* cells;           /* output grid, rows * pitch */
+};
+
 } /* namespace csm */
 #endif

@@ -1113,6 +1113,220 @@ __global__ __launch_bounds__(kBlock) void k_grid_pick(GridSearchJob job)
         atomicMin(job.best_index, (unsigned long long)p);
 }
 
+/* ------------------------------------------------------------------ map building */
+/* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:647-692)
+ * applies, ray after ray, a miss update to every cell the ray crosses and a hit
+ * update to its end cell. A cell update is a function value -> value, so what a
+ * cell ends as depends only on ITS sequence of hits and misses in ray order.
+ * A cell no ray ends in needs just its miss count; for the others the hits are
+ * ranked by ray number and the misses are counted per interval between
+ * consecutive hits. Six small kernels, integer atomics only, no ordering
+ * assumed between threads. */
+
+/* hit cell + sub-pixel end of every ray; the cell's hit counter hands out slots */
+__global__ __launch_bounds__(256) void k_map_hits(MapJob job)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= job.n_rays)
+        return;
+    const MapRay ray = job.rays[r];
+    const int col = cell_index(ray.hx, job.off_x, job.res);
+    const int row = cell_index(ray.hy, job.off_y, job.res);
+    const int ex = cell_index(ray.hx, job.off_x, job.scaled_res);
+    const int ey = cell_index(ray.hy, job.off_y, job.scaled_res);
+    MapRayRec rec = { ex, ey, -1, 0 };
+    const bool ok = col >= 0 && col < job.cols && row >= 0 && row < job.rows && ray.sx >= 0 &&
+                    ray.sy >= 0 && ex >= 0 && ey >= 0 && ex / job.scale < job.cols &&
+                    ey / job.scale < job.rows && ray.sx / job.scale < job.cols &&
+                    ray.sy / job.scale < job.rows;
+    if (ok) {
+        rec.hit_cell = row * job.cols + col;
+        rec.slot = (int)atomicAdd(&job.n_hit[rec.hit_cell], 1u);
+    } else {
+        atomicOr(&job.counters[kMapError], 1ull);   /* the reference asserts (bresenham.cpp:73-76) */
+    }
+    job.recs[r] = rec;
+}
+
+__global__ __launch_bounds__(256) void k_map_alloc(MapJob job)
+{
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= job.rows * job.cols)
+        return;
+    const uint32_t n = job.n_hit[cell];
+    if (n)
+        job.seg[cell] = (uint32_t)atomicAdd(&job.counters[kMapCursor], 3ull * n + 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_map_fill_hits(MapJob job)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= job.n_rays)
+        return;
+    const MapRayRec rec = job.recs[r];
+    if (rec.hit_cell >= 0)
+        job.lists[job.seg[rec.hit_cell] + rec.slot] = (uint32_t)r;
+}
+
+/* rank of each hit among its cell's hits = its place in ray order */
+__global__ __launch_bounds__(256) void k_map_rank_hits(MapJob job)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= job.n_rays)
+        return;
+    const MapRayRec rec = job.recs[r];
+    if (rec.hit_cell < 0)
+        return;
+    const uint32_t n = job.n_hit[rec.hit_cell];
+    const uint32_t* arrival = job.lists + job.seg[rec.hit_cell];
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        rank += arrival[i] < (uint32_t)r;
+    job.lists[job.seg[rec.hit_cell] + n + rank] = (uint32_t)r;
+}
+
+__device__ __forceinline__ void map_miss(const MapJob& job, int x, int y, int skip_x, int skip_y, uint32_t r)
+{
+    if (x == skip_x && y == skip_y)
+        return;                              /* the end cell is taken off the list (grid_map_builder.cpp:904-910) */
+    if (x < 0 || x >= job.cols || y < 0 || y >= job.rows) {
+        atomicOr(&job.counters[kMapError], 2ull);
+        return;
+    }
+    const int cell = y * job.cols + x;
+    const uint32_t n = job.n_hit[cell];
+    if (n == 0) {
+        atomicAdd(&job.n_miss[cell], 1u);
+        return;
+    }
+    /* number of this cell's hits that come before ray r (a ray's own hit comes after its misses) */
+    const uint32_t base = job.seg[cell];
+    const uint32_t* sorted = job.lists + base + n;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    atomicAdd(&job.lists[base + 2 * n + lo], 1u);
+}
+
+/* One wavefront per ray, lanes over the ray's cell columns. The cells are those
+ * of BresenhamScaled (src/bresenham.cpp:58-237) in closed form: with the ray's
+ * height N(x) counted in 1/(2 * scale * dx) cells, column j holds the rows from
+ * where the ray enters it to where it leaves it; a ray that leaves through an
+ * exact cell corner steps diagonally (the corner's other two cells are not
+ * visited). */
+__global__ __launch_bounds__(256) void k_map_walk(MapJob job)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= job.n_rays)
+        return;
+    const MapRayRec rec = job.recs[r];
+    if (rec.hit_cell < 0)
+        return;
+    const int scale = job.scale;
+    int sx = job.rays[r].sx, sy = job.rays[r].sy, ex = rec.ex, ey = rec.ey;
+    const int skip_x = ex / scale, skip_y = ey / scale;
+    if (sx > ex) {                            /* bresenham.cpp:67-70 */
+        int t = sx; sx = ex; ex = t;
+        t = sy; sy = ey; ey = t;
+    }
+    const int x0 = sx / scale, y0 = sy / scale, x1 = ex / scale, y1 = ey / scale;
+    if (x0 == x1) {                           /* bresenham.cpp:87-99 */
+        const int lo = min(y0, y1), hi = max(y0, y1);
+        for (int y = lo + lane; y <= hi; y += 64)
+            map_miss(job, x0, y, skip_x, skip_y, (uint32_t)r);
+        return;
+    }
+    const long long dx = ex - sx, dy = ey - sy;
+    const long long den = 2ll * scale * dx;
+    const long long n0 = (long long)y0 * den + (2ll * (sy % scale) + 1) * dx;
+    const long long first = 2ll * scale - (2ll * (sx % scale) + 1);
+    const long long last = 2ll * (ex % scale) + 1;
+    const int m = x1 - x0;
+    for (int j = lane; j <= m; j += 64) {
+        const long long n_out = j < m ? n0 + dy * (first + 2ll * scale * j)
+                                      : n0 + dy * (first + 2ll * scale * (m - 1) + last);
+        const long long n_in = n0 + dy * (first + 2ll * scale * (j - 1));   /* unused for j = 0 */
+        int from, to;
+        if (dy > 0) {
+            from = j == 0 ? y0 : (int)(n_in / den);
+            to = (int)((n_out + den - 1) / den) - 1;
+        } else {
+            to = j == 0 ? y0 : (int)((n_in + den - 1) / den) - 1;
+            from = (int)(n_out / den);
+        }
+        for (int y = from; y <= to; ++y)
+            map_miss(job, x0 + j, y, skip_x, skip_y, (uint32_t)r);
+    }
+}
+
+/* k updates of one kind; stops at a fixed point. Reads of table entry 65535 are
+ * counted: the reference's odds table ends at 65534 (grid_values.cpp:74-77). */
+__device__ __forceinline__ uint32_t map_iterate(const uint16_t* lut, uint32_t v, uint32_t k, uint32_t& sat)
+{
+    for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t nv = lut[v];
+        if (nv == v) {
+            if (v == 65535u)
+                sat += k - i;
+            break;
+        }
+        sat += v == 65535u;
+        v = nv;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_map_apply(MapJob job)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid / job.pitch, col = gid - row * job.pitch;
+    uint32_t v = 0, sat = 0, updates = 0;
+    const bool live = row < job.rows && col < job.cols;
+    if (live) {
+        const int cell = row * job.cols + col;
+        const uint32_t n = job.n_hit[cell];
+        if (n == 0) {
+            updates = job.n_miss[cell];
+            v = map_iterate(job.lut_miss, 0, updates, sat);
+        } else {
+            const uint32_t* between = job.lists + job.seg[cell] + 2 * n;
+            for (uint32_t i = 0; i <= n; ++i) {
+                updates += between[i];
+                v = map_iterate(job.lut_miss, v, between[i], sat);
+                if (i < n)
+                    v = map_iterate(job.lut_hit, v, 1, sat);
+            }
+            updates += n;
+        }
+    }
+    if (row < job.rows)
+        job.cells[(size_t)row * job.pitch + col] = (uint16_t)v;
+    /* per-wave totals, then one atomic each */
+    uint32_t krow = v ? (uint32_t)row : 0xffffffffu, kcol = v ? (uint32_t)col : 0xffffffffu;
+    for (int off = 32; off; off >>= 1) {
+        sat += __shfl_xor(sat, off);
+        updates += __shfl_xor(updates, off);
+        krow = min(krow, (uint32_t)__shfl_xor(krow, off));
+        kcol = min(kcol, (uint32_t)__shfl_xor(kcol, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (sat)
+            atomicAdd(&job.counters[kMapSaturatedReads], (unsigned long long)sat);
+        if (updates)
+            atomicAdd(&job.counters[kMapUpdates], (unsigned long long)updates);
+        if (krow != 0xffffffffu) {
+            atomicMin(&job.counters[kMapKnownRow], (unsigned long long)krow);
+            atomicMin(&job.counters[kMapKnownCol], (unsigned long long)kcol);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ batch */
 __global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
 {
