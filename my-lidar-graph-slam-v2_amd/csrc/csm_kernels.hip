@@ -1248,20 +1248,45 @@ __global__ __launch_bounds__(256) void k_map_walk(MapJob job)
     const long long first = 2ll * scale - (2ll * (sx % scale) + 1);
     const long long last = 2ll * (ex % scale) + 1;
     const int m = x1 - x0;
-    for (int j = lane; j <= m; j += 64) {
-        const long long n_out = j < m ? n0 + dy * (first + 2ll * scale * j)
-                                      : n0 + dy * (first + 2ll * scale * (m - 1) + last);
-        const long long n_in = n0 + dy * (first + 2ll * scale * (j - 1));   /* unused for j = 0 */
-        int from, to;
-        if (dy > 0) {
-            from = j == 0 ? y0 : (int)(n_in / den);
-            to = (int)((n_out + den - 1) / den) - 1;
-        } else {
-            to = j == 0 ? y0 : (int)((n_in + den - 1) / den) - 1;
-            from = (int)(n_out / den);
+    for (int j0 = 0; j0 <= m; j0 += 64) {
+        const int j = j0 + lane;
+        int from = 0, count = 0;
+        if (j <= m) {
+            const long long n_out = j < m ? n0 + dy * (first + 2ll * scale * j)
+                                          : n0 + dy * (first + 2ll * scale * (m - 1) + last);
+            const long long n_in = n0 + dy * (first + 2ll * scale * (j - 1));   /* unused for j = 0 */
+            int to;
+            if (dy > 0) {
+                from = j == 0 ? y0 : (int)(n_in / den);
+                to = (int)((n_out + den - 1) / den) - 1;
+            } else {
+                to = j == 0 ? y0 : (int)((n_in + den - 1) / den) - 1;
+                from = (int)(n_out / den);
+            }
+            count = to - from + 1;
         }
-        for (int y = from; y <= to; ++y)
-            map_miss(job, x0 + j, y, skip_x, skip_y, (uint32_t)r);
+        /* steep rays have few columns with many rows each: spread the cells of
+         * these 64 columns evenly over the lanes (prefix sum + search) */
+        int incl = count;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off)
+                incl += up;
+        }
+        const int excl = incl - count;
+        const int total = __shfl(incl, 63);
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            int c = 0;                        /* last column whose first cell number is <= t */
+            for (int step = 32; step; step >>= 1) {
+                const int e = __shfl(excl, min(c + step, 63));
+                if (c + step < 64 && e <= t)
+                    c += step;
+            }
+            const int y = __shfl(from, c) + (t - __shfl(excl, c));
+            if (t < total)
+                map_miss(job, x0 + j0 + c, y, skip_x, skip_y, (uint32_t)r);
+        }
     }
 }
 

@@ -23,6 +23,62 @@ using namespace CsmHip;
 template <typename T>
 static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
 
+/* mode 4: GridMapBuilderHIP + ScanMatcherCorrelativeHIP sharing one device
+ * context. File: int32 4, n_nodes, n_beams, patch_size, n_latest, L;
+ * double res, usable_min, usable_max, prob_hit, prob_miss, range_x, range_y, range_t;
+ * double rel[3]; double init_local[3]; per node: double pose[3], min_range,
+ * max_range, angles[n_beams], ranges[n_beams]. Builds the latest map, prints its
+ * geometry and an FNV-1a hash of its cells, then matches the last node's scan. */
+static int run_builder(FILE* f, const int32_t* hdr)
+{
+    const int nNodes = hdr[1], nBeams = hdr[2], patch = hdr[3], nLatest = hdr[4], lowRes = hdr[5];
+    double prm[8], rel[3], init[3];
+    if (!rd(f, prm, 8) || !rd(f, rel, 3) || !rd(f, init, 3))
+        return 2;
+    std::vector<std::vector<double>> angles(nNodes), ranges(nNodes);
+    std::vector<ScanNodeView> nodes(nNodes);
+    for (int k = 0; k < nNodes; ++k) {
+        double head[5];
+        angles[k].resize(nBeams);
+        ranges[k].resize(nBeams);
+        if (!rd(f, head, 5) || !rd(f, angles[k].data(), nBeams) || !rd(f, ranges[k].data(), nBeams))
+            return 2;
+        nodes[k].mNodeId = k;
+        nodes[k].mGlobalPose = { head[0], head[1], head[2] };
+        nodes[k].mMinRange = head[3];
+        nodes[k].mMaxRange = head[4];
+        nodes[k].mScanData.mAngles = angles[k].data();
+        nodes[k].mScanData.mRanges = ranges[k].data();
+        nodes[k].mScanData.mNumOfScans = nBeams;
+        nodes[k].mScanData.mRelativeSensorPose = { rel[0], rel[1], rel[2] };
+    }
+    auto matcher = ScanMatcherCorrelativeHIP::Create("demo", lowRes, prm[5], prm[6], prm[7]);
+    if (!matcher) {
+        std::printf("{\"error\": \"no device\"}\n");
+        return 3;
+    }
+    GridMapBuilderHIP builder(matcher->Context(), prm[0], patch, nLatest, prm[1], prm[2], prm[3], prm[4]);
+    builder.UpdateLatestMap(nodes);
+    const GridMapView& map = builder.LatestMap();
+    const std::vector<uint16_t> cells = builder.CopyLatestMapValues();
+    uint64_t hash = 1469598103934665603ull;
+    for (uint16_t v : cells) {
+        hash = (hash ^ (v & 0xff)) * 1099511628211ull;
+        hash = (hash ^ (v >> 8)) * 1099511628211ull;
+    }
+    ScanMatchingQuery q { map, nodes.back().mScanData, { init[0], init[1], init[2] } };
+    const ScanMatchingSummary r = matcher->OptimizePose(q);
+    std::printf("{\"rows\": %d, \"cols\": %d, \"off\": [\"%a\", \"%a\"], \"hash\": \"%016" PRIx64 "\", "
+                "\"rays\": %lld, \"updates\": %lld, \"map_pose\": [\"%a\", \"%a\", \"%a\"], "
+                "\"found\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\"}\n",
+                map.mRows, map.mCols, map.mPosOffsetX, map.mPosOffsetY, hash,
+                (long long)builder.LastBuildInfo().rays, (long long)builder.LastBuildInfo().cell_updates,
+                builder.LatestMapPose().mX, builder.LatestMapPose().mY, builder.LatestMapPose().mTheta,
+                r.mPoseFound ? 1 : 0, r.mEstimatedPose.mX, r.mEstimatedPose.mY, r.mEstimatedPose.mTheta,
+                r.mScoreValue);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2)
@@ -33,7 +89,14 @@ int main(int argc, char** argv)
     int32_t hdr[6];
     double prm[8], rel[3];
     double step[3] = { 0.0, 0.0, 0.0 };
-    if (!rd(f, hdr, 6) || !rd(f, prm, 8) || (hdr[0] == 3 && !rd(f, step, 3)) || !rd(f, rel, 3))
+    if (!rd(f, hdr, 6))
+        return 2;
+    if (hdr[0] == 4) {
+        const int rc = run_builder(f, hdr);
+        std::fclose(f);
+        return rc;
+    }
+    if (false || !rd(f, prm, 8) || (hdr[0] == 3 && !rd(f, step, 3)) || !rd(f, rel, 3))
         return 2;
     const int mode = hdr[0], rows = hdr[1], cols = hdr[2], n = hdr[3], nq = hdr[4], pi = hdr[5];
     std::vector<double> init(3 * nq), angles(n), ranges(n);

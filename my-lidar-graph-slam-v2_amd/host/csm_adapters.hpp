@@ -7,8 +7,11 @@
  *   LoopDetectorBranchBoundHIP  <- LoopDetectorBranchBound (search part)
  *        inc/mapping/loop_detector_branch_bound.hpp:71-112, loop_detector.hpp:97-116
  *   LoopDetectorCorrelativeHIP  <- LoopDetectorCorrelative (search part)
- *   ScanMatcherGridSearchHIP    <- ScanMatcherGridSearch
  *        inc/mapping/loop_detector_correlative.hpp, src/mapping/loop_detector_correlative.cpp:59-156
+ *   ScanMatcherGridSearchHIP    <- ScanMatcherGridSearch
+ *        inc/mapping/scan_matcher_grid_search.hpp, src/mapping/scan_matcher_grid_search.cpp:69-190
+ *   GridMapBuilderHIP           <- GridMapBuilder (latest-map part)
+ *        inc/mapping/grid_map_builder.hpp, src/mapping/grid_map_builder.cpp:497-527, 561-695
  *
  * The reference headers cannot be included in this image (Eigen3 / Boost are
  * absent), so the few value types the interfaces use are restated here in
@@ -24,6 +27,8 @@
 #ifndef CSM_ADAPTERS_HPP
 #define CSM_ADAPTERS_HPP
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -175,6 +180,8 @@ public:
     ScanMatcherCorrelativeHIP& operator=(const ScanMatcherCorrelativeHIP&) = delete;
 
     const std::string& Name() const { return this->mName; }
+    /* the device context, to share resident maps with a GridMapBuilderHIP */
+    csm_ctx* Context() const { return this->mCtx.get(); }
 
     /* ScanMatcher::OptimizePose (scan_matcher_correlative.cpp:92-115): the whole
      * window, thresholds 0.0 / 0.0 */
@@ -495,6 +502,108 @@ private:
     const double mRangeX, mRangeY, mRangeTheta;
     const double mScoreThreshold, mKnownRateThreshold;
     detail::CtxPtr mCtx;
+};
+
+/* What the map update reads of a ScanNode (inc/mapping/pose_graph.hpp) and its
+ * ScanData (inc/sensor/sensor_data.hpp:63-185) */
+struct ScanNodeView {
+    int mNodeId = 0;
+    RobotPose2D<double> mGlobalPose { 0.0, 0.0, 0.0 };
+    ScanDataView mScanData;
+    double mMinRange = 0.0, mMaxRange = 0.0;
+};
+
+/* The latest-map half of GridMapBuilder (src/mapping/grid_map_builder.cpp): the
+ * map the frontend matches every new scan against is rebuilt from the last
+ * mNumOfScansForLatestMap scans on every call (UpdateLatestMap, :497-527).
+ * Here it is built on the device and stays there under one map id, so the
+ * matcher needs no upload; pass the matcher's Context() to share it. */
+class GridMapBuilderHIP final {
+public:
+    /* constructor arguments as GridMapBuilder (grid_map_builder.cpp:68-99) minus
+     * the local-map ones; `ctx` is borrowed */
+    GridMapBuilderHIP(csm_ctx* ctx, double mapResolution, int patchSize, int numOfScansForLatestMap,
+                      double usableRangeMin, double usableRangeMax, double probHit,
+                      double probMiss, std::uint64_t latestMapId = (1ull << 61)) :
+        mCtx(ctx), mNumOfScansForLatestMap(numOfScansForLatestMap), mLatestMapPose { 0.0, 0.0, 0.0 }
+    {
+        this->mParams = { usableRangeMin, usableRangeMax, probHit, probMiss, 100 };   /* SubpixelScale */
+        /* GridMap(resolution, patchSize, 1.0, 1.0) (grid_map.cpp:75-98, 224-246) */
+        int log2Block = 0;
+        while ((1 << log2Block) < patchSize)
+            ++log2Block;
+        const int block = 1 << log2Block;
+        const int desired = static_cast<int>(std::ceil(1.0 / mapResolution));
+        const int cells = ((desired + block - 1) >> log2Block) << log2Block;
+        this->mShape = { mapResolution, 0.0, 0.0, cells, cells, log2Block };
+        this->mLatestMap.mId = latestMapId;
+        this->SyncView();
+    }
+
+    /* geometry + id of the latest map; mValues is null: the cells live on the device */
+    const GridMapView& LatestMap() const { return this->mLatestMap; }
+    const RobotPose2D<double>& LatestMapPose() const { return this->mLatestMapPose; }
+    const csm_map_build_info& LastBuildInfo() const { return this->mInfo; }
+
+    /* GridMapBuilder::UpdateLatestMap (grid_map_builder.cpp:497-527); scanNodes in id order */
+    void UpdateLatestMap(const std::vector<ScanNodeView>& scanNodes)
+    {
+        if (scanNodes.empty()) {
+            std::fprintf(stderr, "Assertion failed: !scanNodes.empty() at %s:%d\n", __FILE__, __LINE__);
+            std::abort();
+        }
+        const std::size_t count = std::min(scanNodes.size(),
+                                           static_cast<std::size_t>(this->mNumOfScansForLatestMap));
+        const ScanNodeView* first = scanNodes.data() + (scanNodes.size() - count);
+        this->mLatestMapPose = first->mGlobalPose;
+        this->ConstructMapFromScans(this->mLatestMapPose, first, count);
+    }
+
+    /* GridMapBuilder::ConstructMapFromScans (grid_map_builder.cpp:561-695) into the latest map */
+    void ConstructMapFromScans(const RobotPose2D<double>& globalMapPose, const ScanNodeView* nodes,
+                               std::size_t numOfNodes)
+    {
+        std::vector<csm_scan_node> flat(numOfNodes);
+        for (std::size_t i = 0; i < numOfNodes; ++i) {
+            flat[i].global_pose[0] = nodes[i].mGlobalPose.mX;
+            flat[i].global_pose[1] = nodes[i].mGlobalPose.mY;
+            flat[i].global_pose[2] = nodes[i].mGlobalPose.mTheta;
+            flat[i].scan = detail::ToScan(nodes[i].mScanData);
+            flat[i].min_range = nodes[i].mMinRange;
+            flat[i].max_range = nodes[i].mMaxRange;
+        }
+        const double pose[3] = { globalMapPose.mX, globalMapPose.mY, globalMapPose.mTheta };
+        CSM_ASSERT_OK(this->mCtx, csm_construct_map_from_scans(
+                                      this->mCtx, this->mLatestMap.mId, &this->mShape, pose, flat.data(),
+                                      static_cast<std::int32_t>(numOfNodes), &this->mParams, &this->mInfo));
+        this->SyncView();
+    }
+
+    /* GridMap::CopyValues of the latest map (grid_map.cpp:439-457) */
+    std::vector<std::uint16_t> CopyLatestMapValues() const
+    {
+        std::vector<std::uint16_t> values(static_cast<std::size_t>(this->mShape.rows) * this->mShape.cols);
+        CSM_ASSERT_OK(this->mCtx, csm_download_level(this->mCtx, this->mLatestMap.mId, 0, values.data()));
+        return values;
+    }
+
+private:
+    void SyncView()
+    {
+        this->mLatestMap.mRows = this->mShape.rows;
+        this->mLatestMap.mCols = this->mShape.cols;
+        this->mLatestMap.mResolution = this->mShape.resolution;
+        this->mLatestMap.mPosOffsetX = this->mShape.offset_x;
+        this->mLatestMap.mPosOffsetY = this->mShape.offset_y;
+    }
+
+    csm_ctx* mCtx;
+    int mNumOfScansForLatestMap;
+    RobotPose2D<double> mLatestMapPose;
+    csm_map_builder_params mParams {};
+    csm_map_shape mShape {};
+    csm_map_build_info mInfo {};
+    GridMapView mLatestMap;
 };
 
 } /* namespace CsmHip */

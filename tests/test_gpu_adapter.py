@@ -107,3 +107,42 @@ def test_cpp_grid_search_adapter(tmp_path, oracle):
     assert got["found"] == want["found"] == 1
     assert [float.fromhex(v) for v in got["pose"]] == want["estimatedPose"]
     assert float.fromhex(got["score"]) == want["scoreMax"]
+
+
+def test_cpp_grid_map_builder_adapter(tmp_path, oracle):
+    """GridMapBuilderHIP::UpdateLatestMap (last 10 of 12 nodes) + the matcher on
+    the device-resident result, through the C++ adapters."""
+    case = synth.map_case(8, n_scans=12, n_beams=360, rel_pose=(0.05, 0.0, 0.01))
+    nodes = case["nodes"]
+    latest = nodes[-10:]
+    map_pose = latest[0]["pose"]
+    want_shape, want_grid, stats = oracle.construct_map(case["shape"], map_pose, latest)
+    last = nodes[-1]
+    c, s_ = math.cos(map_pose[2]), math.sin(map_pose[2])
+    dx, dy = last["pose"][0] + 0.07 - map_pose[0], last["pose"][1] - 0.05 - map_pose[1]
+    init = (c * dx + s_ * dy, -s_ * dx + c * dy, last["pose"][2] + 0.01 - map_pose[2])
+    p = str(tmp_path / "gmb.bin")
+    with open(p, "wb") as f:
+        f.write(struct.pack("<6i", 4, len(nodes), 360, 16, 10, 4))
+        f.write(struct.pack("<8d", 0.05, 0.01, 20.0, 0.62, 0.46, 1.0, 1.0, 0.25))
+        f.write(struct.pack("<3d", *last["rel_pose"]))
+        f.write(struct.pack("<3d", *init))
+        for nd in nodes:
+            f.write(struct.pack("<5d", *nd["pose"], nd["min_range"], nd["max_range"]))
+            f.write(np.asarray(nd["angles"], np.float64).tobytes())
+            f.write(np.asarray(nd["ranges"], np.float64).tobytes())
+    got = _run(p)
+    assert (got["rows"], got["cols"]) == (want_shape["rows"], want_shape["cols"])
+    assert [float.fromhex(v) for v in got["off"]] == [want_shape["off_x"], want_shape["off_y"]]
+    h = 1469598103934665603
+    for b in want_grid.astype("<u2").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert got["hash"] == "%016x" % h
+    assert (got["rays"], got["updates"]) == (stats["rays"], stats["updates"])
+    assert [float.fromhex(v) for v in got["map_pose"]] == list(map_pose)
+    geom = (want_shape["res"], want_shape["off_x"], want_shape["off_y"])
+    want = oracle.csm(dict(grid=want_grid, geom=geom, angles=last["angles"], ranges=last["ranges"],
+                           rel_pose=last["rel_pose"], init_pose=init), 1.0, 1.0, 0.25, 4)
+    assert got["found"] == want["found"] == 1
+    assert [float.fromhex(v) for v in got["pose"]] == want["estimatedPose"]
+    assert float.fromhex(got["score"]) == want["scoreMax"]

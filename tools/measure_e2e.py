@@ -126,6 +126,19 @@ def main():
     out["grid_search_default_window"] = dict(
         ms_per_call=dt * 1e3, candidates=r["candidates"], poses_per_s=r["candidates"] / dt,
         kernel_ms=ctx.kernel_time("grid_search")[0], found=r["pose_found"])
+    # map building: the frontend's latest map, 10 scans x 1080 beams
+    mc = synth.map_case(2, n_scans=10, n_beams=1080)
+    shape, info = ctx.construct_map_from_scans(77, mc["shape"], mc["map_pose"], mc["nodes"])
+    ctx.reset_kernel_timing()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _, info = ctx.construct_map_from_scans(77, shape, mc["map_pose"], mc["nodes"])
+    dt = (time.perf_counter() - t0) / reps
+    out["map_build_10x1080"] = dict(ms_per_call=dt * 1e3, rays=info["rays"], cell_updates=info["cell_updates"],
+                                    updates_per_s=info["cell_updates"] / dt, host_us=info["host_us"],
+                                    device_us=info["device_us"],
+                                    kernel_ms=ctx.kernel_time("map_build")[0] / reps)
     print(json.dumps(out, indent=1))
 
 
