@@ -173,15 +173,121 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse):
     ctx.close()
 
 
+def run_map_workload(args, rank, world, dev, dev_index, rehearse):
+    """SURVEY 8(f) rank 4, the frontend cycle: a step = rebuild the latest map
+    from the last 10 scans (10 x 1080 beams, csm_construct_map_from_scans; scans
+    arrive as host arrays like the reference's ScanData) + match the newest scan
+    against the device-resident result (csm_correlative_match, +-0.5 m / 0.25 rad).
+    Ranks are independent replicas. Not the BASELINE metric."""
+    import torch
+    import torch.distributed as dist
+    from csm_hip import api, synth
+    ctx = api.Context(dev_index)
+    mc = synth.map_case(2 + rank, n_scans=10, n_beams=1080)
+    shape, info = ctx.construct_map_from_scans(7, mc["shape"], mc["map_pose"], mc["nodes"])
+    last = mc["nodes"][-1]
+    mp = mc["map_pose"]
+    c, s_ = math.cos(mp[2]), math.sin(mp[2])
+    dx, dy = last["pose"][0] + 0.07 - mp[0], last["pose"][1] - 0.05 - mp[1]
+    init = (c * dx + s_ * dy, -s_ * dx + c * dy, last["pose"][2] + 0.01 - mp[2])
+
+    split = [0.0, 0.0]
+
+    def step():
+        t_a = time.perf_counter()
+        sh, inf = ctx.construct_map_from_scans(7, shape, mc["map_pose"], mc["nodes"])
+        t_b = time.perf_counter()
+        out = ctx.correlative_match(7, (sh["res"], sh["off_x"], sh["off_y"]), last["angles"], last["ranges"],
+                                    last["rel_pose"], init, 1.0, 1.0, 0.25, 4, 0.0, 0.0)
+        split[0] += t_b - t_a
+        split[1] += time.perf_counter() - t_b
+        return inf, out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(1, args.warmup)):
+        info, out = step()
+    fence()
+    # the per-step marshalling allocates enough Python objects to trigger a full
+    # collection of torch's large heap (one ~50 ms pause per ~50 steps): keep
+    # the collector out of the timed region
+    import gc
+    gc.collect()
+    gc.disable()
+    split[0] = split[1] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info, out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    split_timed = [split[0] / args.steps * 1e3, split[1] / args.steps * 1e3]
+    # kernel breakdown from a few extra steps with the event timers on (they
+    # allocate events per launch, so they stay out of the timed region)
+    k_steps = 10
+    ctx.enable_kernel_timing(True)
+    step()
+    ctx.reset_kernel_timing()
+    for _ in range(k_steps):
+        step()
+    fence()
+    ctx.enable_kernel_timing(False)
+    build_ms, build_n = ctx.kernel_time("map_build")
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        line = {
+            "metric": "map cell updates/sec (latest-map build + match per step)",
+            "value": info["cell_updates"] * args.steps * world / dt, "unit": "cell updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "frontend cycle: ConstructMapFromScans of 10 x 1080 beams (%d x %d cells, "
+                                   "%d rays, %d cell updates) + ScanMatcherCorrelative on the resident map; "
+                                   "host-inclusive calls" % (shape["rows"], shape["cols"], info["rays"],
+                                                             info["cell_updates"]),
+                       "map_kernels_us_per_step": build_ms / max(1, build_n) * 1e3,
+                       "build_ms_per_step": split_timed[0],
+                       "match_ms_per_step": split_timed[1],
+                       "match_kernels_us": {k: ctx.kernel_time(k)[0] / k_steps * 1e3 for k in
+                                            ("boxmax", "project", "bin", "score_coarse", "score_fine",
+                                             "finalize")},
+                       "match_found": out["pose_found"], "match_flags": out["raw"]["flags"],
+                       "match_tie_count": out["raw"]["tie_count"],
+                       "match_setup_us": out["input_setup_us"], "match_optimization_us": out["optimization_us"],
+                       "parallelism": "independent replicas" if world > 1 else "single GPU"},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 5.0:
+                oracle.construct_map(mc["shape"], mc["map_pose"], mc["nodes"])
+                reps += 1
+            cdt = (time.perf_counter() - t0) / reps
+            line["cpu_baseline"] = dict(value=info["cell_updates"] / cdt, unit="cell updates/s", cores=1,
+                                        kind="port", sample="%d builds of the same 10 scans, map build only, "
+                                        "%.2f ms each" % (reps, cdt * 1e3))
+        print(json.dumps(line), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["csm", "loop"], default="csm",
+    ap.add_argument("--workload", choices=["csm", "loop", "map"], default="csm",
                     help="csm (default): BASELINE configs[1]; loop: configs[2]/[3], 256 candidate "
-                         "submaps per GPU through the branch-and-bound batch + all-gather")
+                         "submaps per GPU through the branch-and-bound batch + all-gather; map: the "
+                         "frontend cycle (latest-map build from 10 scans + match), not the BASELINE metric")
     args = ap.parse_args()
 
     import numpy as np
@@ -210,8 +316,9 @@ def main():
     ge.build()          # file-locked: ranks take turns, later ones find it built
     from csm_hip import api, _lib
 
-    if args.workload == "loop":
-        run_loop_workload(args, rank, world, dev, dev_index, rehearse)
+    if args.workload in ("loop", "map"):
+        (run_loop_workload if args.workload == "loop" else run_map_workload)(
+            args, rank, world, dev, dev_index, rehearse)
         if world > 1:
             dist.destroy_process_group()
         return

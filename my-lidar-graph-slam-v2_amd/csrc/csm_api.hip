@@ -2372,7 +2372,7 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
             hipLaunchKernelGGL(k_map_alloc, dim3(cell_blocks), dim3(256), 0, ctx->stream, mj);
             hipLaunchKernelGGL(k_map_fill_hits, dim3(ray_blocks), dim3(256), 0, ctx->stream, mj);
             hipLaunchKernelGGL(k_map_rank_hits, dim3(ray_blocks), dim3(256), 0, ctx->stream, mj);
-            hipLaunchKernelGGL(k_map_walk, dim3((unsigned)ceil_div(n_rays, 4)), dim3(256), 0, ctx->stream, mj);
+            hipLaunchKernelGGL(k_map_walk, dim3((unsigned)ceil_div(n_rays, kMapGroup)), dim3(512), 0, ctx->stream, mj);
         }
         hipLaunchKernelGGL(k_map_apply, dim3((unsigned)(((size_t)rows * pitch + 255) / 256)), dim3(256), 0,
                            ctx->stream, mj);

@@ -1185,7 +1185,15 @@ __global__ __launch_bounds__(256) void k_map_rank_hits(MapJob job)
     job.lists[job.seg[rec.hit_cell] + n + rank] = (uint32_t)r;
 }
 
-__device__ __forceinline__ void map_miss(const MapJob& job, int x, int y, int skip_x, int skip_y, uint32_t r)
+/* the rays of one workgroup of k_map_walk count the misses of hit-free cells
+ * inside this window in LDS first */
+struct MapWindow {
+    int x_lo, y_lo, w, h;
+    uint32_t* count;
+};
+
+__device__ __forceinline__ void map_miss(const MapJob& job, const MapWindow& win, int x, int y,
+                                         int skip_x, int skip_y, uint32_t r)
 {
     if (x == skip_x && y == skip_y)
         return;                              /* the end cell is taken off the list (grid_map_builder.cpp:904-910) */
@@ -1196,7 +1204,11 @@ __device__ __forceinline__ void map_miss(const MapJob& job, int x, int y, int sk
     const int cell = y * job.cols + x;
     const uint32_t n = job.n_hit[cell];
     if (n == 0) {
-        atomicAdd(&job.n_miss[cell], 1u);
+        const int wx = x - win.x_lo, wy = y - win.y_lo;
+        if ((unsigned)wx < (unsigned)win.w && (unsigned)wy < (unsigned)win.h)
+            atomicAdd(&win.count[wy * win.w + wx], 1u);
+        else
+            atomicAdd(&job.n_miss[cell], 1u);
         return;
     }
     /* number of this cell's hits that come before ray r (a ray's own hit comes after its misses) */
@@ -1219,12 +1231,8 @@ __device__ __forceinline__ void map_miss(const MapJob& job, int x, int y, int sk
  * where the ray enters it to where it leaves it; a ray that leaves through an
  * exact cell corner steps diagonally (the corner's other two cells are not
  * visited). */
-__global__ __launch_bounds__(256) void k_map_walk(MapJob job)
+__device__ __forceinline__ void map_walk_ray(const MapJob& job, const MapWindow& win, int r, int lane)
 {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= job.n_rays)
-        return;
     const MapRayRec rec = job.recs[r];
     if (rec.hit_cell < 0)
         return;
@@ -1239,7 +1247,7 @@ __global__ __launch_bounds__(256) void k_map_walk(MapJob job)
     if (x0 == x1) {                           /* bresenham.cpp:87-99 */
         const int lo = min(y0, y1), hi = max(y0, y1);
         for (int y = lo + lane; y <= hi; y += 64)
-            map_miss(job, x0, y, skip_x, skip_y, (uint32_t)r);
+            map_miss(job, win, x0, y, skip_x, skip_y, (uint32_t)r);
         return;
     }
     const long long dx = ex - sx, dy = ey - sy;
@@ -1285,7 +1293,71 @@ __global__ __launch_bounds__(256) void k_map_walk(MapJob job)
             }
             const int y = __shfl(from, c) + (t - __shfl(excl, c));
             if (t < total)
-                map_miss(job, x0 + j0 + c, y, skip_x, skip_y, (uint32_t)r);
+                map_miss(job, win, x0 + j0 + c, y, skip_x, skip_y, (uint32_t)r);
+        }
+    }
+}
+
+/* kMapGroup consecutive rays per workgroup (neighbouring beams of one scan: they
+ * cross the same cells near the sensor). Device-scope atomics execute at the
+ * memory side and are the rate limit of this step, so the group first counts
+ * in an LDS window over its rays' bounding box and then adds each non-zero
+ * counter once, row-contiguous. */
+constexpr int kMapGroup = 32;
+constexpr int kMapWindowCells = 12288;       /* 48 KB */
+
+__global__ __launch_bounds__(512) void k_map_walk(MapJob job)
+{
+    __shared__ int box[6];                   /* x_lo, y_lo, x_hi, y_hi, anchor x, anchor y */
+    __shared__ uint32_t window[kMapWindowCells];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * kMapGroup;
+    if (tid == 0) {
+        box[0] = box[1] = 0x7fffffff;
+        box[2] = box[3] = box[4] = box[5] = -1;
+    }
+    __syncthreads();
+    if (tid < kMapGroup && r0 + tid < job.n_rays) {
+        const MapRayRec rec = job.recs[r0 + tid];
+        if (rec.hit_cell >= 0) {
+            const int ax = job.rays[r0 + tid].sx / job.scale, ay = job.rays[r0 + tid].sy / job.scale;
+            const int bx = rec.ex / job.scale, by = rec.ey / job.scale;
+            atomicMin(&box[0], min(ax, bx));
+            atomicMin(&box[1], min(ay, by));
+            atomicMax(&box[2], max(ax, bx));
+            atomicMax(&box[3], max(ay, by));
+            atomicMax(&box[4], ax);          /* any one sensor cell of the group */
+            atomicMax(&box[5], ay);
+        }
+    }
+    __syncthreads();
+    MapWindow win = { box[0], box[1], box[2] - box[0] + 1, box[3] - box[1] + 1, window };
+    if (box[2] < 0)
+        return;                              /* no usable ray in this group (uniform) */
+    if ((long long)win.w * win.h > kMapWindowCells) {
+        /* too large: keep the part around the sensor, where the rays overlap most */
+        const double f = 0.95 * sqrt((double)kMapWindowCells / ((double)win.w * win.h));
+        const int ax = min(max(box[4], box[0]), box[2]), ay = min(max(box[5], box[1]), box[3]);
+        const int x_lo = ax - (int)((ax - box[0]) * f), x_hi = ax + (int)((box[2] - ax) * f);
+        const int y_lo = ay - (int)((ay - box[1]) * f), y_hi = ay + (int)((box[3] - ay) * f);
+        win.x_lo = x_lo;
+        win.y_lo = y_lo;
+        win.w = min(x_hi - x_lo + 1, kMapWindowCells);
+        win.h = min(y_hi - y_lo + 1, kMapWindowCells / win.w);
+    }
+    const int cells = win.w * win.h;
+    for (int i = tid; i < cells; i += 512)
+        window[i] = 0;
+    __syncthreads();
+    for (int k = wave; k < kMapGroup; k += 8)
+        if (r0 + k < job.n_rays)
+            map_walk_ray(job, win, r0 + k, lane);
+    __syncthreads();
+    for (int i = tid; i < cells; i += 512) {
+        const uint32_t c = window[i];
+        if (c) {
+            const int wy = i / win.w, wx = i - wy * win.w;
+            atomicAdd(&job.n_miss[(win.y_lo + wy) * job.cols + win.x_lo + wx], c);
         }
     }
 }

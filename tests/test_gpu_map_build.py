@@ -25,7 +25,8 @@ def _check(gpu_ctx, oracle, case, map_id, **kw):
     assert info["cell_updates"] == stats["updates"]
     assert info["saturated_reads"] == stats["oob_reads"]
     ys, xs = np.nonzero(want_grid)
-    assert (info["first_known_row"], info["first_known_col"]) == (ys.min(), xs.min())
+    first = (ys.min(), xs.min()) if ys.size else want_grid.shape      # nothing known: rows / cols
+    assert (info["first_known_row"], info["first_known_col"]) == first
     return shape, got, info
 
 
@@ -96,3 +97,53 @@ def test_map_rejects_bad_input(gpu_ctx):
     with pytest.raises(api.CsmError):
         gpu_ctx.construct_map_from_scans(340, case["shape"], case["map_pose"], case["nodes"], subpixel_scale=0)
     assert not gpu_ctx.has_grid(340)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_map_randomised(gpu_ctx, oracle, seed):
+    """Random trajectories, resolutions, block sizes, sub-pixel scales, sensor
+    offsets, range noise and starting frames; every cell must agree."""
+    rng = np.random.RandomState(1000 + seed)
+    res = float(rng.choice([0.025, 0.05, 0.1, 0.2]))
+    case = synth.map_case(seed, n_scans=int(rng.randint(1, 8)), n_beams=int(rng.choice([64, 181, 360, 500])),
+                          fov=float(rng.choice([math.pi, 1.5 * math.pi, 2 * math.pi])),
+                          max_range=float(rng.choice([3.0, 6.0, 12.0])), res=res,
+                          step=float(rng.choice([0.0, 0.05, 0.3])),
+                          rel_pose=tuple(rng.uniform(-0.2, 0.2, 3)), noise=float(rng.choice([0.0, 0.02])))
+    shape = dict(case["shape"])
+    shape["log2_block"] = int(rng.choice([2, 3, 4, 5]))
+    n = 1 << shape["log2_block"]
+    shape["rows"] = shape["cols"] = -(-int(math.ceil(1.0 / res)) // n) * n
+    # a frame left behind by earlier builds: any offset on the block lattice or off it
+    shape["off_x"] = float(rng.choice([0.0, -3.2, 1.6, 0.0137]))
+    shape["off_y"] = float(rng.choice([0.0, 4.8, -0.8, -0.0219]))
+    case["shape"] = shape
+    kw = dict(usable_range_max=float(rng.choice([2.5, 20.0])), usable_range_min=float(rng.choice([0.01, 0.5])),
+              prob_hit=float(rng.choice([0.55, 0.62, 0.9])), prob_miss=float(rng.choice([0.1, 0.46, 0.49])),
+              subpixel_scale=int(rng.choice([1, 7, 100, 1000])))
+    try:
+        oracle.construct_map(case["shape"], case["map_pose"], case["nodes"], usable_min=kw["usable_range_min"],
+                             usable_max=kw["usable_range_max"])
+    except ValueError:
+        # nothing usable: the bounding box is empty and the reference asserts
+        with pytest.raises(api.CsmError):
+            gpu_ctx.construct_map_from_scans(400 + seed, case["shape"], case["map_pose"], case["nodes"], **kw)
+        return
+    _check(gpu_ctx, oracle, case, 400 + seed, **kw)
+    gpu_ctx.release_grid(400 + seed)
+
+
+def test_map_aligned_geometry(gpu_ctx, oracle):
+    """Sensor and walls on exact multiples of the resolution: hit points on cell
+    edges, rays through cell corners."""
+    segs = [(-2.0, -1.5, 2.0, -1.5), (2.0, -1.5, 2.0, 1.5), (2.0, 1.5, -2.0, 1.5), (-2.0, 1.5, -2.0, -1.5)]
+    nodes = []
+    for k, pose in enumerate([(0.0, 0.0, 0.0), (0.25, 0.0, math.pi / 2), (0.25, 0.25, math.pi / 4)]):
+        angles, ranges = synth.cast_scan(segs, pose, 720, 2 * math.pi, 10.0)
+        nodes.append(dict(pose=pose, angles=angles, ranges=ranges, rel_pose=(0.0, 0.0, 0.0),
+                          min_range=0.0, max_range=9.0))
+    case = dict(nodes=nodes, map_pose=(0.0, 0.0, 0.0),
+                shape=dict(res=0.25, off_x=0.0, off_y=0.0, rows=8, cols=8, log2_block=2))
+    for scale in (1, 2, 100):
+        _check(gpu_ctx, oracle, case, 440, subpixel_scale=scale)
+    gpu_ctx.release_grid(440)
