@@ -319,8 +319,11 @@ typedef struct {
                                    (grid_values.cpp:74-77) has no such entry (undefined behaviour
                                    there); this library extends the table's formula */
     int32_t first_known_row, first_known_col;
-    double  host_us;            /* hit points (glibc sin/cos) + resize */
-    double  device_us;          /* upload + kernels */
+    int32_t device_projection;  /* 1: hit points computed on the device under a certificate (the few
+                                   uncertifiable beams redone with glibc); 0: all on the host */
+    int32_t reserved;
+    double  host_us;            /* poses, projection round trip, resize */
+    double  device_us;          /* upload + kernels of the update */
 } csm_map_build_info;
 
 /* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:561-695)

@@ -73,6 +73,7 @@ class MapShape(C.Structure):
 class MapBuildInfo(C.Structure):
     _fields_ = [("rays", C.c_int64), ("cell_updates", C.c_int64), ("saturated_reads", C.c_int64),
                 ("first_known_row", C.c_int32), ("first_known_col", C.c_int32),
+                ("device_projection", C.c_int32), ("reserved", C.c_int32),
                 ("host_us", C.c_double), ("device_us", C.c_double)]
 
 

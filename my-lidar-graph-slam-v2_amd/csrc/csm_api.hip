@@ -2149,6 +2149,7 @@ namespace {
 /* GridBinaryBayes's conversions (src/grid_map_new/grid_binary_bayes.cpp:345-383,
  * inc/grid_map_new/grid_values.hpp:11-46) with its constants: values 1..65535
  * stand for probabilities 0.001..0.999, 0 = unknown. */
+constexpr uint32_t kMapUncCap = 4096;    /* beams listed for exact recomputation per build */
 const double kBayesProbMin = 1e-3;
 const double kBayesProbMax = 1.0 - 1e-3;
 
@@ -2207,14 +2208,12 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     const auto t0 = std::chrono::steady_clock::now();
     const int scale = prm->subpixel_scale;
     const double res = shape->resolution;
+    const double scaled_res = res / scale;                  /* ScaledGeometry, grid_map_geometry.cpp:46-58 */
+    auto to_index = [res](double p, double off) { return static_cast<int>(std::floor((p - off) / res)); };
 
-    /* grid_map_builder.cpp:583-638: sensor poses, usable hit points, bounding box */
-    double min_x = std::numeric_limits<double>::max(), min_y = min_x;
-    double max_x = std::numeric_limits<double>::min(), max_y = max_x;   /* as the reference: smallest positive */
-    struct NodeSensor { double x, y; };
-    std::vector<NodeSensor> sensors(n_nodes);
-    std::vector<MapRay> rays;
-    std::vector<int32_t> ray_node;
+    /* grid_map_builder.cpp:583-612: sensor poses, usable ranges */
+    std::vector<MapNode> table(n_nodes);
+    long long n_beams_ll = 0, usable = 0;
     for (int k = 0; k < n_nodes; ++k) {
         const csm_scan_node& nd = nodes[k];
         if (!nd.scan.angles || !nd.scan.ranges || nd.scan.n_points < 0)
@@ -2222,40 +2221,173 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
         double global_sensor[3], local_sensor[3];
         csm_host_compound(nd.global_pose, nd.scan.relative_sensor_pose, global_sensor);
         csm_host_inverse_compound(global_map_pose, global_sensor, local_sensor);
-        sensors[k] = { local_sensor[0], local_sensor[1] };
-        min_x = std::min(min_x, local_sensor[0]);
-        min_y = std::min(min_y, local_sensor[1]);
-        max_x = std::max(max_x, local_sensor[0]);
-        max_y = std::max(max_y, local_sensor[1]);
-        const double min_range = std::max(prm->usable_range_min, nd.min_range);
-        const double max_range = std::min(prm->usable_range_max, nd.max_range);
+        MapNode& t = table[k];
+        t.x = local_sensor[0];
+        t.y = local_sensor[1];
+        t.theta = local_sensor[2];
+        t.min_range = std::max(prm->usable_range_min, nd.min_range);
+        t.max_range = std::min(prm->usable_range_max, nd.max_range);
+        t.beam_base = (int32_t)n_beams_ll;
+        t.n_beams = nd.scan.n_points;
+        t.sx = t.sy = 0;
+        n_beams_ll += nd.scan.n_points;
         for (int i = 0; i < nd.scan.n_points; ++i) {
             const double r = nd.scan.ranges[i];
-            if (r >= max_range || r <= min_range)
-                continue;
-            /* ScanData::HitPoint (inc/sensor/sensor_data.hpp:189-203) */
-            const double c = std::cos(local_sensor[2] + nd.scan.angles[i]);
-            const double s = std::sin(local_sensor[2] + nd.scan.angles[i]);
-            MapRay ray;
-            ray.hx = local_sensor[0] + r * c;
-            ray.hy = local_sensor[1] + r * s;
-            ray.sx = ray.sy = 0;
-            rays.push_back(ray);
-            ray_node.push_back(k);
-            min_x = std::min(min_x, ray.hx);
-            min_y = std::min(min_y, ray.hy);
-            max_x = std::max(max_x, ray.hx);
-            max_y = std::max(max_y, ray.hy);
+            usable += !(r >= t.max_range || r <= t.min_range);
         }
     }
-    if (!(min_x < max_x) || !(min_y < max_y))
-        return fail(ctx, CSM_EINVAL, "empty bounding box (the reference asserts)");
+    if (n_beams_ll > (1ll << 24))
+        return fail(ctx, CSM_EINVAL, "%lld beams in one map build", n_beams_ll);
+    const int n_beams = (int)n_beams_ll;
+    const int n_rays = n_beams;             /* a ray's number = its beam's place in the update order */
 
-    /* GridMap::Resize, both overloads (grid_map.cpp:841-913), on the CURRENT geometry */
-    auto to_index = [res](double p, double off) { return static_cast<int>(std::floor((p - off) / res)); };
+    int rc = 0;
+    if ((rc = ensure(ctx, ctx->m_rays, (size_t)std::max(n_rays, 1) * sizeof(MapRay) +
+                                           (size_t)n_nodes * sizeof(MapNode) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->m_recs, (size_t)std::max(n_rays, 1) * sizeof(MapRayRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->m_lists, (4 * (size_t)n_rays + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->m_cnt, kMapCounters * sizeof(unsigned long long) + 64 + kMapUncCap * 4))) return rc;
+    MapRay* d_rays = reinterpret_cast<MapRay*>(ctx->m_rays.p);
+    MapNode* d_nodes = reinterpret_cast<MapNode*>(d_rays + std::max(n_rays, 1));
+    unsigned long long* d_counters = reinterpret_cast<unsigned long long*>(ctx->m_cnt.p);
+    int32_t* d_box = reinterpret_cast<int32_t*>(d_counters + kMapCounters);   /* [4] + count + spread */
+    uint32_t* d_unc = reinterpret_cast<uint32_t*>(d_box + 4);                  /* [0] count, [1] spread bits */
+    uint32_t* d_unc_list = d_unc + 4;
+
+    /* ---- hit points + bounding box (grid_map_builder.cpp:614-638) ----
+     * In index form: Resize(BoundingBox<double>) (grid_map.cpp:892-913) takes
+     * floor((min - res - off) / res) and floor((max + res - off) / res), and that
+     * expression is monotone, so the box is the min / max of it over the points. */
+    int box[4] = { 0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1 };
+    double min_x = std::numeric_limits<double>::max(), min_y = min_x;
+    double max_x = std::numeric_limits<double>::min(), max_y = max_x;   /* as the reference: smallest positive */
+    auto add_point = [&](double x, double y) {
+        min_x = std::min(min_x, x);
+        min_y = std::min(min_y, y);
+        max_x = std::max(max_x, x);
+        max_y = std::max(max_y, y);
+    };
+    for (const MapNode& t : table)
+        add_point(t.x, t.y);
+    bool device_projection = n_beams > 0 && !std::getenv("CSM_MAP_HOST_PROJECTION");
+    uint32_t unc_cap = kMapUncCap;
+    if (const char* e = std::getenv("CSM_MAP_UNC_CAP"))     /* test knob */
+        unc_cap = (uint32_t)std::min<long>(std::max<long>(std::atol(e), 0), kMapUncCap);
+    bool spread_known = false;              /* the box of the certified beams is certainly not degenerate */
+    if (device_projection) {
+        /* scans to the device (one staging copy), projection there */
+        std::vector<double> stage(2 * (size_t)n_beams);
+        for (int k = 0; k < n_nodes; ++k) {
+            std::memcpy(stage.data() + table[k].beam_base, nodes[k].scan.angles,
+                        (size_t)table[k].n_beams * sizeof(double));
+            std::memcpy(stage.data() + n_beams + table[k].beam_base, nodes[k].scan.ranges,
+                        (size_t)table[k].n_beams * sizeof(double));
+        }
+        if ((rc = ensure(ctx, ctx->scan_dev, stage.size() * sizeof(double)))) return rc;
+        double* d_scan = reinterpret_cast<double*>(ctx->scan_dev.p);
+        const int32_t init_box[8] = { box[0], box[1], box[2], box[3], 0, 0, 0, 0 };
+        HIP_TRY(ctx, hipMemcpyAsync(d_scan, stage.data(), stage.size() * sizeof(double),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_nodes, table.data(), table.size() * sizeof(MapNode),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_box, init_box, sizeof(init_box), hipMemcpyHostToDevice, ctx->stream));
+        MapProjJob pj;
+        std::memset(&pj, 0, sizeof(pj));
+        pj.angles = d_scan;
+        pj.ranges = d_scan + n_beams;
+        pj.nodes = d_nodes;
+        pj.n_nodes = n_nodes;
+        pj.n_beams = n_beams;
+        pj.rays = d_rays;
+        pj.off_x = shape->offset_x;
+        pj.off_y = shape->offset_y;
+        pj.res = res;
+        pj.scaled_res = scaled_res;
+        pj.box = d_box;
+        pj.unc_count = d_unc;
+        pj.unc_list = d_unc_list;
+        pj.unc_cap = unc_cap;
+        {
+            ScopedTimer tm(ctx, "map_project");
+            hipLaunchKernelGGL(k_map_project, dim3((unsigned)ceil_div(n_beams, 256)), dim3(256), 0, ctx->stream, pj);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        int32_t got[8];
+        HIP_TRY(ctx, hipMemcpyAsync(got, d_box, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t n_unc = (uint32_t)got[4];
+        spread_known = ((uint32_t)got[5] & 3u) == 3u;
+        if (n_unc > unc_cap || !spread_known) {
+            device_projection = false;      /* too many beams on cell edges, or a degenerate box: all on the host */
+        } else {
+            for (int k = 0; k < 4; ++k)
+                box[k] = got[k];
+            if (n_unc) {
+                /* the beams the device could not certify: exactly as the reference, and patched in */
+                std::vector<uint32_t> list(n_unc);
+                std::vector<MapRay> exact(n_unc);
+                HIP_TRY(ctx, hipMemcpy(list.data(), d_unc_list, (size_t)n_unc * 4, hipMemcpyDeviceToHost));
+                for (uint32_t u = 0; u < n_unc; ++u) {
+                    const uint32_t b = list[u];
+                    int k = 0;
+                    while (k + 1 < n_nodes && table[k + 1].beam_base <= (int32_t)b)
+                        ++k;
+                    const int i = (int)b - table[k].beam_base;
+                    const double r = nodes[k].scan.ranges[i];
+                    MapRay& ray = exact[u];
+                    ray.hx = table[k].x + r * std::cos(table[k].theta + nodes[k].scan.angles[i]);
+                    ray.hy = table[k].y + r * std::sin(table[k].theta + nodes[k].scan.angles[i]);
+                    ray.node = k;
+                    ray.usable = 1;
+                    add_point(ray.hx, ray.hy);
+                    HIP_TRY(ctx, hipMemcpyAsync(d_rays + b, &ray, sizeof(ray), hipMemcpyHostToDevice, ctx->stream));
+                }
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   /* `exact` goes out of scope */
+            }
+        }
+    }
+    if (!device_projection) {
+        /* host projection (ScanData::HitPoint, inc/sensor/sensor_data.hpp:189-203) */
+        std::vector<MapRay> rays((size_t)std::max(n_rays, 1));
+        for (int k = 0; k < n_nodes; ++k) {
+            const MapNode& t = table[k];
+            for (int i = 0; i < t.n_beams; ++i) {
+                MapRay& ray = rays[(size_t)t.beam_base + i];
+                ray.hx = ray.hy = 0.0;
+                ray.node = k;
+                ray.usable = 0;
+                const double r = nodes[k].scan.ranges[i];
+                if (r >= t.max_range || r <= t.min_range)
+                    continue;
+                ray.hx = t.x + r * std::cos(t.theta + nodes[k].scan.angles[i]);
+                ray.hy = t.y + r * std::sin(t.theta + nodes[k].scan.angles[i]);
+                ray.usable = 1;
+                add_point(ray.hx, ray.hy);
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            box[k] = k < 2 ? 0x7fffffff : -0x7fffffff - 1;
+        if (n_rays) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_rays, rays.data(), (size_t)n_rays * sizeof(MapRay),
+                                        hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       /* `rays` goes out of scope */
+        }
+        spread_known = false;
+    }
+    /* Assert(min < max) of Resize: the host-side points decide unless the certified
+     * beams are known to spread in both axes */
+    if (!spread_known && (!(min_x < max_x) || !(min_y < max_y)))
+        return fail(ctx, CSM_EINVAL, "empty bounding box (the reference asserts)");
+    if (min_x <= max_x) {                   /* points the host holds as doubles (always: the sensors) */
+        box[0] = std::min(box[0], to_index(min_x - res, shape->offset_x));
+        box[1] = std::min(box[1], to_index(min_y - res, shape->offset_y));
+        box[2] = std::max(box[2], to_index(max_x + res, shape->offset_x));
+        box[3] = std::max(box[3], to_index(max_y + res, shape->offset_y));
+    }
+
+    /* GridMap::Resize(BoundingBox<int>) (grid_map.cpp:841-889) on the CURRENT geometry */
     const int lb = shape->log2_block_size, block = 1 << lb;
-    const int i_min_x = to_index(min_x - res, shape->offset_x), i_min_y = to_index(min_y - res, shape->offset_y);
-    const int i_max_x = to_index(max_x + res, shape->offset_x) + 1, i_max_y = to_index(max_y + res, shape->offset_y) + 1;
+    const int i_min_x = box[0], i_min_y = box[1], i_max_x = box[2] + 1, i_max_y = box[3] + 1;
     const int b_min_x = map_index_to_block(i_min_x, lb), b_min_y = map_index_to_block(i_min_y, lb);
     const int b_max_x = map_index_to_block(i_max_x + block - 1, lb);
     const int b_max_y = map_index_to_block(i_max_y + block - 1, lb);
@@ -2266,17 +2398,13 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     /* GridMapGeometry::Resize (grid_map_geometry.cpp:61-72) */
     const double off_x = shape->offset_x + res * (b_min_x << lb);
     const double off_y = shape->offset_y + res * (b_min_y << lb);
-    const double scaled_res = res / scale;                  /* ScaledGeometry, :46-58 */
-    for (size_t i = 0; i < rays.size(); ++i) {
-        const NodeSensor& sn = sensors[ray_node[i]];
-        rays[i].sx = static_cast<int>(std::floor((sn.x - off_x) / scaled_res));
-        rays[i].sy = static_cast<int>(std::floor((sn.y - off_y) / scaled_res));
+    for (MapNode& t : table) {
+        t.sx = static_cast<int>(std::floor((t.x - off_x) / scaled_res));
+        t.sy = static_cast<int>(std::floor((t.y - off_y) / scaled_res));
     }
-    const int n_rays = (int)rays.size();
     const size_t n_cells = (size_t)rows * cols;
 
     /* the two value -> value tables of the cell update */
-    int rc = 0;
     if ((rc = ensure(ctx, ctx->m_lut, 2 * 65536 * sizeof(uint16_t)))) return rc;
     uint16_t* d_lut = reinterpret_cast<uint16_t*>(ctx->m_lut.p);
     if (ctx->m_lut_hit != prm->prob_hit || ctx->m_lut_miss != prm->prob_miss) {
@@ -2323,14 +2451,11 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     g.known_r0 = 0;
     g.known_c0 = 0;
 
-    if ((rc = ensure(ctx, ctx->m_rays, (size_t)std::max(n_rays, 1) * sizeof(MapRay)))) return rc;
-    if ((rc = ensure(ctx, ctx->m_recs, (size_t)std::max(n_rays, 1) * sizeof(MapRayRec)))) return rc;
     if ((rc = ensure(ctx, ctx->m_cell, 3 * n_cells * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->m_lists, (4 * (size_t)n_rays + 4) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->m_cnt, kMapCounters * sizeof(unsigned long long)))) return rc;
     MapJob mj;
     std::memset(&mj, 0, sizeof(mj));
-    mj.rays = reinterpret_cast<const MapRay*>(ctx->m_rays.p);
+    mj.rays = d_rays;
+    mj.nodes = d_nodes;
     mj.recs = reinterpret_cast<MapRayRec*>(ctx->m_recs.p);
     mj.n_rays = n_rays;
     mj.off_x = off_x;
@@ -2345,7 +2470,7 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     mj.n_miss = mj.n_hit + n_cells;
     mj.seg = mj.n_miss + n_cells;
     mj.lists = reinterpret_cast<uint32_t*>(ctx->m_lists.p);
-    mj.counters = reinterpret_cast<unsigned long long*>(ctx->m_cnt.p);
+    mj.counters = d_counters;
     mj.lut_hit = d_lut;
     mj.lut_miss = d_lut + 65536;
     mj.cells = g.levels[0].cells;
@@ -2357,9 +2482,8 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
         HIP_TRY(ctx, hipEventCreate(&ev_b));
         HIP_TRY(ctx, hipEventRecord(ev_a, ctx->stream));
     }
-    if (n_rays)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->m_rays.p, rays.data(), (size_t)n_rays * sizeof(MapRay),
-                                    hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_nodes, table.data(), table.size() * sizeof(MapNode),
+                                hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mj.counters, counters, sizeof(counters), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(mj.n_hit, 0, 2 * n_cells * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(mj.lists, 0, (4 * (size_t)n_rays + 4) * sizeof(uint32_t), ctx->stream));
@@ -2401,11 +2525,12 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     shape->offset_x = off_x;
     shape->offset_y = off_y;
     if (info) {
-        info->rays = n_rays;
+        info->rays = usable;
         info->cell_updates = (int64_t)counters[kMapUpdates];
         info->saturated_reads = (int64_t)counters[kMapSaturatedReads];
         info->first_known_row = g.known_r0;
         info->first_known_col = g.known_c0;
+        info->device_projection = device_projection ? 1 : 0;
         info->host_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
         info->device_us = dev_ms * 1e3;
     }

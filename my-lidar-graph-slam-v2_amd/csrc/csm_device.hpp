@@ -234,8 +234,15 @@ struct GridSearchJob {
 /* Map building from scans (GridMapBuilder::ConstructMapFromScans). A ray is one
  * usable beam of one scan node, numbered in the reference's update order. */
 struct MapRay {
-    double  hx, hy;            /* hit point, map-local (host, glibc) */
-    int32_t sx, sy;            /* sub-pixel index of its node's sensor position */
+    double  hx, hy;            /* hit point, map-local */
+    int32_t node;              /* its scan node */
+    int32_t usable;            /* range inside (min, max): grid_map_builder.cpp:618-619 */
+};
+struct MapNode {
+    double  x, y, theta;       /* sensor pose, map-local (host) */
+    double  min_range, max_range;
+    int32_t beam_base, n_beams;
+    int32_t sx, sy;            /* sub-pixel index of the sensor position (set after the resize) */
 };
 struct MapRayRec {
     int32_t ex, ey;            /* sub-pixel index of the hit point */
@@ -246,8 +253,23 @@ enum MapCounter {
     kMapCursor = 0, kMapError, kMapSaturatedReads, kMapUpdates, kMapKnownRow, kMapKnownCol,
     kMapCounters
 };
+/* hit points on the device with a certificate (see k_map_project) */
+struct MapProjJob {
+    const double* angles;      /* all nodes' beams, concatenated */
+    const double* ranges;
+    const MapNode* nodes;
+    int32_t n_nodes, n_beams;
+    MapRay* rays;
+    double off_x, off_y, res, scaled_res;    /* the map's frame BEFORE the resize */
+    int32_t* box;              /* [4] min / max of floor((h -+ res - off) / res) over certified beams */
+    uint32_t* unc_count;
+    uint32_t* unc_list;
+    uint32_t unc_cap;
+};
+
 struct MapJob {
     const MapRay* rays;
+    const MapNode* nodes;
     MapRayRec* recs;
     int32_t n_rays;
     double  off_x, off_y, res, scaled_res;

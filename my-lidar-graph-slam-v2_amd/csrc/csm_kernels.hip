@@ -1114,6 +1114,8 @@ __global__ __launch_bounds__(kBlock) void k_grid_pick(GridSearchJob job)
 }
 
 /* ------------------------------------------------------------------ map building */
+__device__ __forceinline__ double proj_err_bound(double r, double hit, double off, double res, double q);
+
 /* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:647-692)
  * applies, ray after ray, a miss update to every cell the ray crosses and a hit
  * update to its end cell. A cell update is a function value -> value, so what a
@@ -1123,6 +1125,77 @@ __global__ __launch_bounds__(kBlock) void k_grid_pick(GridSearchJob job)
  * consecutive hits. Six small kernels, integer atomics only, no ordering
  * assumed between threads. */
 
+/* ScanData::HitPoint for every beam (grid_map_builder.cpp:614-630) with the
+ * device's sin / cos. Only integers derived from the hit point are used later --
+ * floor((h - off) / res) at the cell and the sub-pixel resolution, in the frame
+ * the resize will choose, and floor((h -+ res - off) / res) for the bounding box
+ * -- and all of them are q + (a whole number) up to roundings of ~1e-12 cells,
+ * where q is the same expression in the CURRENT frame. A beam whose q (cell and
+ * sub-pixel scale, both axes) stays farther from the next integer than the two
+ * libms can disagree plus that slack gives the host's integers; the others are
+ * listed and recomputed on the host with glibc. */
+__device__ __forceinline__ bool map_certified(double r, double h, double off, double res)
+{
+    const double q = (h - off) / res;
+    const double m = 64.0 * proj_err_bound(r, h, off, res, q) +
+                     64.0 * 2.3e-16 * (fabs(h) + fabs(off) + 1.0e3) / res;
+    const double frac = q - floor(q);
+    return frac > m && frac < 1.0 - m;
+}
+
+__global__ __launch_bounds__(256) void k_map_project(MapProjJob job)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = -0x7fffffff - 1, hi_y = -0x7fffffff - 1;
+    if (b < job.n_beams) {
+        /* the node of this beam: nodes are few, beams ordered by node */
+        int k = 0;
+        while (k + 1 < job.n_nodes && job.nodes[k + 1].beam_base <= b)
+            ++k;
+        const MapNode nd = job.nodes[k];
+        const double r = job.ranges[b];
+        MapRay ray = { 0.0, 0.0, k, 0 };
+        if (!(r >= nd.max_range || r <= nd.min_range)) {
+            const double arg = nd.theta + job.angles[b];
+            ray.hx = nd.x + r * cos(arg);
+            ray.hy = nd.y + r * sin(arg);
+            ray.usable = 1;
+            /* clearly off the sensor position in x / y: the bounding box is not degenerate */
+            const uint32_t spread = (fabs(ray.hx - nd.x) > 1e-6 ? 1u : 0u) | (fabs(ray.hy - nd.y) > 1e-6 ? 2u : 0u);
+            if (spread & ~job.unc_count[1])
+                atomicOr(&job.unc_count[1], spread);
+            const bool sure = map_certified(r, ray.hx, job.off_x, job.res) &&
+                              map_certified(r, ray.hy, job.off_y, job.res) &&
+                              map_certified(r, ray.hx, job.off_x, job.scaled_res) &&
+                              map_certified(r, ray.hy, job.off_y, job.scaled_res);
+            if (sure) {
+                /* GridMap::Resize(BoundingBox<double>) (grid_map.cpp:892-913) is monotone in h */
+                lo_x = cell_index(ray.hx - job.res, job.off_x, job.res);
+                lo_y = cell_index(ray.hy - job.res, job.off_y, job.res);
+                hi_x = cell_index(ray.hx + job.res, job.off_x, job.res);
+                hi_y = cell_index(ray.hy + job.res, job.off_y, job.res);
+            } else {
+                const uint32_t pos = atomicAdd(job.unc_count, 1u);
+                if (pos < job.unc_cap)
+                    job.unc_list[pos] = (uint32_t)b;
+            }
+        }
+        job.rays[b] = ray;
+    }
+    for (int off = 32; off; off >>= 1) {
+        lo_x = min(lo_x, __shfl_xor(lo_x, off));
+        lo_y = min(lo_y, __shfl_xor(lo_y, off));
+        hi_x = max(hi_x, __shfl_xor(hi_x, off));
+        hi_y = max(hi_y, __shfl_xor(hi_y, off));
+    }
+    if ((threadIdx.x & 63) == 0 && lo_x != 0x7fffffff) {
+        atomicMin(&job.box[0], lo_x);
+        atomicMin(&job.box[1], lo_y);
+        atomicMax(&job.box[2], hi_x);
+        atomicMax(&job.box[3], hi_y);
+    }
+}
+
 /* hit cell + sub-pixel end of every ray; the cell's hit counter hands out slots */
 __global__ __launch_bounds__(256) void k_map_hits(MapJob job)
 {
@@ -1130,20 +1203,23 @@ __global__ __launch_bounds__(256) void k_map_hits(MapJob job)
     if (r >= job.n_rays)
         return;
     const MapRay ray = job.rays[r];
-    const int col = cell_index(ray.hx, job.off_x, job.res);
-    const int row = cell_index(ray.hy, job.off_y, job.res);
-    const int ex = cell_index(ray.hx, job.off_x, job.scaled_res);
-    const int ey = cell_index(ray.hy, job.off_y, job.scaled_res);
-    MapRayRec rec = { ex, ey, -1, 0 };
-    const bool ok = col >= 0 && col < job.cols && row >= 0 && row < job.rows && ray.sx >= 0 &&
-                    ray.sy >= 0 && ex >= 0 && ey >= 0 && ex / job.scale < job.cols &&
-                    ey / job.scale < job.rows && ray.sx / job.scale < job.cols &&
-                    ray.sy / job.scale < job.rows;
-    if (ok) {
-        rec.hit_cell = row * job.cols + col;
-        rec.slot = (int)atomicAdd(&job.n_hit[rec.hit_cell], 1u);
-    } else {
-        atomicOr(&job.counters[kMapError], 1ull);   /* the reference asserts (bresenham.cpp:73-76) */
+    MapRayRec rec = { 0, 0, -1, 0 };
+    if (ray.usable) {
+        const int sx = job.nodes[ray.node].sx, sy = job.nodes[ray.node].sy;
+        const int col = cell_index(ray.hx, job.off_x, job.res);
+        const int row = cell_index(ray.hy, job.off_y, job.res);
+        rec.ex = cell_index(ray.hx, job.off_x, job.scaled_res);
+        rec.ey = cell_index(ray.hy, job.off_y, job.scaled_res);
+        const bool ok = col >= 0 && col < job.cols && row >= 0 && row < job.rows && sx >= 0 && sy >= 0 &&
+                        rec.ex >= 0 && rec.ey >= 0 && rec.ex / job.scale < job.cols &&
+                        rec.ey / job.scale < job.rows && sx / job.scale < job.cols &&
+                        sy / job.scale < job.rows;
+        if (ok) {
+            rec.hit_cell = row * job.cols + col;
+            rec.slot = (int)atomicAdd(&job.n_hit[rec.hit_cell], 1u);
+        } else {
+            atomicOr(&job.counters[kMapError], 1ull);   /* the reference asserts (bresenham.cpp:73-76) */
+        }
     }
     job.recs[r] = rec;
 }
@@ -1237,7 +1313,8 @@ __device__ __forceinline__ void map_walk_ray(const MapJob& job, const MapWindow&
     if (rec.hit_cell < 0)
         return;
     const int scale = job.scale;
-    int sx = job.rays[r].sx, sy = job.rays[r].sy, ex = rec.ex, ey = rec.ey;
+    const MapNode& node = job.nodes[job.rays[r].node];
+    int sx = node.sx, sy = node.sy, ex = rec.ex, ey = rec.ey;
     const int skip_x = ex / scale, skip_y = ey / scale;
     if (sx > ex) {                            /* bresenham.cpp:67-70 */
         int t = sx; sx = ex; ex = t;
@@ -1320,7 +1397,8 @@ __global__ __launch_bounds__(512) void k_map_walk(MapJob job)
     if (tid < kMapGroup && r0 + tid < job.n_rays) {
         const MapRayRec rec = job.recs[r0 + tid];
         if (rec.hit_cell >= 0) {
-            const int ax = job.rays[r0 + tid].sx / job.scale, ay = job.rays[r0 + tid].sy / job.scale;
+            const MapNode& node = job.nodes[job.rays[r0 + tid].node];
+            const int ax = node.sx / job.scale, ay = node.sy / job.scale;
             const int bx = rec.ex / job.scale, by = rec.ey / job.scale;
             atomicMin(&box[0], min(ax, bx));
             atomicMin(&box[1], min(ay, by));

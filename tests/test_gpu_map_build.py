@@ -133,9 +133,22 @@ def test_map_randomised(gpu_ctx, oracle, seed):
     gpu_ctx.release_grid(400 + seed)
 
 
-def test_map_aligned_geometry(gpu_ctx, oracle):
+def test_map_projection_paths(gpu_ctx, oracle, monkeypatch):
+    """The hit points come from the device under a certificate; forcing the host
+    projection must give the same map."""
+    case = synth.map_case(31, n_scans=5, n_beams=500, noise=0.01)
+    _, grid, info = _check(gpu_ctx, oracle, case, 450)
+    assert info["device_projection"] == 1
+    monkeypatch.setenv("CSM_MAP_HOST_PROJECTION", "1")
+    _, grid2, info2 = _check(gpu_ctx, oracle, case, 450)
+    assert info2["device_projection"] == 0 and np.array_equal(grid, grid2)
+    gpu_ctx.release_grid(450)
+
+
+def test_map_aligned_geometry(gpu_ctx, oracle, monkeypatch):
     """Sensor and walls on exact multiples of the resolution: hit points on cell
-    edges, rays through cell corners."""
+    edges (the device cannot certify them: they are redone on the host, or, past
+    the list's capacity, everything is), rays through cell corners."""
     segs = [(-2.0, -1.5, 2.0, -1.5), (2.0, -1.5, 2.0, 1.5), (2.0, 1.5, -2.0, 1.5), (-2.0, 1.5, -2.0, -1.5)]
     nodes = []
     for k, pose in enumerate([(0.0, 0.0, 0.0), (0.25, 0.0, math.pi / 2), (0.25, 0.25, math.pi / 4)]):
@@ -145,5 +158,28 @@ def test_map_aligned_geometry(gpu_ctx, oracle):
     case = dict(nodes=nodes, map_pose=(0.0, 0.0, 0.0),
                 shape=dict(res=0.25, off_x=0.0, off_y=0.0, rows=8, cols=8, log2_block=2))
     for scale in (1, 2, 100):
-        _check(gpu_ctx, oracle, case, 440, subpixel_scale=scale)
+        _, _, info = _check(gpu_ctx, oracle, case, 440, subpixel_scale=scale)
+        assert info["device_projection"] == 1
+    monkeypatch.setenv("CSM_MAP_UNC_CAP", "3")
+    _, _, info = _check(gpu_ctx, oracle, case, 440, subpixel_scale=100)
+    assert info["device_projection"] == 0           # more than 3 beams sit on cell edges
     gpu_ctx.release_grid(440)
+
+
+def test_map_degenerate_boxes(gpu_ctx, oracle):
+    """One scan whose only usable beams point along one axis: the bounding box
+    is decided from exact host values."""
+    angles = np.array([0.0, 0.0, 0.0])              # all along +x: sin(0) = 0 exactly
+    ranges = np.array([2.0, 3.0, 1.5])
+    node = dict(pose=(0.3, 0.2, 0.0), angles=angles, ranges=ranges, rel_pose=(0.0, 0.0, 0.0),
+                min_range=0.0, max_range=10.0)
+    shape = dict(res=0.05, off_x=0.0, off_y=0.0, rows=32, cols=32, log2_block=4)
+    case = dict(nodes=[node], map_pose=(0.0, 0.0, 0.0), shape=shape)
+    with pytest.raises(ValueError):
+        oracle.construct_map(shape, case["map_pose"], case["nodes"])     # y extent is empty: Assert
+    with pytest.raises(api.CsmError):
+        gpu_ctx.construct_map_from_scans(460, shape, case["map_pose"], case["nodes"])
+    two = dict(case)
+    two["nodes"] = [node, dict(node, pose=(0.3, 0.7, 0.0))]              # a second sensor position opens it
+    _check(gpu_ctx, oracle, two, 460)
+    gpu_ctx.release_grid(460)
