@@ -74,6 +74,7 @@ struct csm_ctx {
     /* map building */
     DevBuf m_rays, m_recs, m_cell, m_lists, m_cnt, m_lut;
     double m_lut_hit = -1.0, m_lut_miss = -1.0;   /* probabilities the update tables were built for */
+    bool m_apply_attr = false;
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -2245,7 +2246,9 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     if ((rc = ensure(ctx, ctx->m_rays, (size_t)std::max(n_rays, 1) * sizeof(MapRay) +
                                            (size_t)n_nodes * sizeof(MapNode) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->m_recs, (size_t)std::max(n_rays, 1) * sizeof(MapRayRec)))) return rc;
-    if ((rc = ensure(ctx, ctx->m_lists, (4 * (size_t)n_rays + 4) * sizeof(uint32_t)))) return rc;
+    /* per hit cell at most 3n + 7 words (csm_device.hpp: map_block_words), then the hit-cell list */
+    const size_t list_words = 10 * (size_t)n_rays + 16;
+    if ((rc = ensure(ctx, ctx->m_lists, (list_words + (size_t)n_rays + 4) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->m_cnt, kMapCounters * sizeof(unsigned long long) + 64 + kMapUncCap * 4))) return rc;
     MapRay* d_rays = reinterpret_cast<MapRay*>(ctx->m_rays.p);
     MapNode* d_nodes = reinterpret_cast<MapNode*>(d_rays + std::max(n_rays, 1));
@@ -2405,6 +2408,12 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     const size_t n_cells = (size_t)rows * cols;
 
     /* the two value -> value tables of the cell update */
+    if (!ctx->m_apply_attr) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_map_apply_hits),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         65536 * (int)sizeof(uint16_t)));
+        ctx->m_apply_attr = true;
+    }
     if ((rc = ensure(ctx, ctx->m_lut, 2 * 65536 * sizeof(uint16_t)))) return rc;
     uint16_t* d_lut = reinterpret_cast<uint16_t*>(ctx->m_lut.p);
     if (ctx->m_lut_hit != prm->prob_hit || ctx->m_lut_miss != prm->prob_miss) {
@@ -2470,11 +2479,13 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     mj.n_miss = mj.n_hit + n_cells;
     mj.seg = mj.n_miss + n_cells;
     mj.lists = reinterpret_cast<uint32_t*>(ctx->m_lists.p);
+    mj.hit_cells = mj.lists + list_words;
     mj.counters = d_counters;
     mj.lut_hit = d_lut;
     mj.lut_miss = d_lut + 65536;
     mj.cells = g.levels[0].cells;
-    unsigned long long counters[kMapCounters] = { 0, 0, 0, 0, ~0ull, ~0ull };
+    unsigned long long counters[kMapCounters] = { 0 };
+    counters[kMapKnownRow] = counters[kMapKnownCol] = ~0ull;
     const auto t1 = std::chrono::steady_clock::now();
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     if (info) {
@@ -2486,7 +2497,6 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
                                 hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mj.counters, counters, sizeof(counters), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(mj.n_hit, 0, 2 * n_cells * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(mj.lists, 0, (4 * (size_t)n_rays + 4) * sizeof(uint32_t), ctx->stream));
     {
         ScopedTimer tm(ctx, "map_build");
         const unsigned ray_blocks = (unsigned)ceil_div(std::max(n_rays, 1), 256);
@@ -2500,6 +2510,13 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
         }
         hipLaunchKernelGGL(k_map_apply, dim3((unsigned)(((size_t)rows * pitch + 255) / 256)), dim3(256), 0,
                            ctx->stream, mj);
+        if (usable > 0) {
+            /* one workgroup per CU at most; the kernel spreads the cells with hits over
+             * their wavefronts (each has at least one usable ray) */
+            const unsigned wgs = (unsigned)std::min<long long>(
+                256, ceil_div((int)std::min<long long>(usable, (long long)n_cells), 4));
+            hipLaunchKernelGGL(k_map_apply_hits, dim3(wgs), dim3(256), 65536 * sizeof(uint16_t), ctx->stream, mj);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     if (info)
@@ -2526,8 +2543,11 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     shape->offset_y = off_y;
     if (info) {
         info->rays = usable;
-        info->cell_updates = (int64_t)counters[kMapUpdates];
-        info->saturated_reads = (int64_t)counters[kMapSaturatedReads];
+        info->cell_updates = info->saturated_reads = 0;
+        for (int k = 0; k < kMapStripes; ++k) {
+            info->cell_updates += (int64_t)counters[kMapStripedUpdates + k];
+            info->saturated_reads += (int64_t)counters[kMapStripedSaturated + k];
+        }
         info->first_known_row = g.known_r0;
         info->first_known_col = g.known_c0;
         info->device_projection = device_projection ? 1 : 0;

@@ -251,8 +251,19 @@ struct MapRayRec {
 };
 enum MapCounter {
     kMapCursor = 0, kMapError, kMapSaturatedReads, kMapUpdates, kMapKnownRow, kMapKnownCol,
-    kMapCounters
+    kMapHitCells,
+    /* update / saturation totals are striped over kMapStripes words each: same-address
+     * atomics serialise at the memory side (~100 per microsecond) */
+    kMapStripedUpdates, kMapStripedSaturated = kMapStripedUpdates + 64,
+    kMapCounters = kMapStripedSaturated + 64
 };
+/* words from a hit cell's block start to its misses_between[] (16-byte aligned) */
+__host__ __device__ inline uint32_t map_between_offset(uint32_t n) { return (2u * n + 3u) & ~3u; }
+__host__ __device__ inline uint32_t map_block_words(uint32_t n)
+{
+    return map_between_offset(n) + ((n + 1u + 3u) & ~3u);
+}
+
 /* hit points on the device with a certificate (see k_map_project) */
 struct MapProjJob {
     const double* angles;      /* all nodes' beams, concatenated */
@@ -267,6 +278,7 @@ struct MapProjJob {
     uint32_t unc_cap;
 };
 
+constexpr int kMapStripes = 64;
 struct MapJob {
     const MapRay* rays;
     const MapNode* nodes;
@@ -278,7 +290,9 @@ struct MapJob {
     uint32_t* n_hit;           /* [rows * cols] hits ending in the cell */
     uint32_t* n_miss;          /* [rows * cols] misses of cells no ray ends in */
     uint32_t* seg;             /* [rows * cols] start of the cell's block in `lists` */
-    uint32_t* lists;           /* per cell with n hits: arrival[n] sorted[n] misses_between[n + 1] */
+    uint32_t* lists;           /* per cell with n hits: arrival[n] sorted[n] (padded to 4 words)
+                                  misses_between[n + 1] (padded to 4 words); see map_between_offset */
+    uint32_t* hit_cells;       /* [<= n_rays] the cells with hits, any order */
     unsigned long long* counters;   /* [kMapCounters] */
     const uint16_t* lut_hit;   /* value -> value after one hit / miss update */
     const uint16_t* lut_miss;

@@ -1227,11 +1227,36 @@ __global__ __launch_bounds__(256) void k_map_hits(MapJob job)
 __global__ __launch_bounds__(256) void k_map_alloc(MapJob job)
 {
     const int cell = blockIdx.x * 256 + threadIdx.x;
-    if (cell >= job.rows * job.cols)
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = cell < job.rows * job.cols ? job.n_hit[cell] : 0u;
+    /* one pair of atomics per wavefront: prefix sums of the block sizes and of the hit cells */
+    uint32_t words = n ? map_block_words(n) : 0u, cells = n ? 1u : 0u;
+    uint32_t words_incl = words, cells_incl = cells;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t w = __shfl_up(words_incl, off), c = __shfl_up(cells_incl, off);
+        if (lane >= off) {
+            words_incl += w;
+            cells_incl += c;
+        }
+    }
+    const uint32_t words_total = __shfl(words_incl, 63), cells_total = __shfl(cells_incl, 63);
+    if (cells_total == 0)
         return;
-    const uint32_t n = job.n_hit[cell];
-    if (n)
-        job.seg[cell] = (uint32_t)atomicAdd(&job.counters[kMapCursor], 3ull * n + 1ull);
+    uint32_t words_base = 0, cells_base = 0;
+    if (lane == 0) {
+        words_base = (uint32_t)atomicAdd(&job.counters[kMapCursor], (unsigned long long)words_total);
+        cells_base = (uint32_t)atomicAdd(&job.counters[kMapHitCells], (unsigned long long)cells_total);
+    }
+    words_base = __shfl(words_base, 0);
+    cells_base = __shfl(cells_base, 0);
+    if (n) {
+        const uint32_t base = words_base + words_incl - words;
+        job.seg[cell] = base;
+        job.hit_cells[cells_base + cells_incl - 1] = (uint32_t)cell;
+        uint4* between = reinterpret_cast<uint4*>(job.lists + base + map_between_offset(n));
+        for (uint32_t i = 0; i < (n + 4u) / 4u; ++i)
+            between[i] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_map_fill_hits(MapJob job)
@@ -1298,7 +1323,7 @@ __device__ __forceinline__ void map_miss(const MapJob& job, const MapWindow& win
         else
             hi = mid;
     }
-    atomicAdd(&job.lists[base + 2 * n + lo], 1u);
+    atomicAdd(&job.lists[base + map_between_offset(n) + lo], 1u);
 }
 
 /* One wavefront per ray, lanes over the ray's cell columns. The cells are those
@@ -1457,32 +1482,10 @@ __device__ __forceinline__ uint32_t map_iterate(const uint16_t* lut, uint32_t v,
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_map_apply(MapJob job)
+/* per-wave totals of k_map_apply / k_map_apply_hits, one atomic each */
+__device__ __forceinline__ void map_apply_totals(const MapJob& job, uint32_t v, int row, int col,
+                                                 uint32_t sat, uint32_t updates)
 {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int row = gid / job.pitch, col = gid - row * job.pitch;
-    uint32_t v = 0, sat = 0, updates = 0;
-    const bool live = row < job.rows && col < job.cols;
-    if (live) {
-        const int cell = row * job.cols + col;
-        const uint32_t n = job.n_hit[cell];
-        if (n == 0) {
-            updates = job.n_miss[cell];
-            v = map_iterate(job.lut_miss, 0, updates, sat);
-        } else {
-            const uint32_t* between = job.lists + job.seg[cell] + 2 * n;
-            for (uint32_t i = 0; i <= n; ++i) {
-                updates += between[i];
-                v = map_iterate(job.lut_miss, v, between[i], sat);
-                if (i < n)
-                    v = map_iterate(job.lut_hit, v, 1, sat);
-            }
-            updates += n;
-        }
-    }
-    if (row < job.rows)
-        job.cells[(size_t)row * job.pitch + col] = (uint16_t)v;
-    /* per-wave totals, then one atomic each */
     uint32_t krow = v ? (uint32_t)row : 0xffffffffu, kcol = v ? (uint32_t)col : 0xffffffffu;
     for (int off = 32; off; off >>= 1) {
         sat += __shfl_xor(sat, off);
@@ -1491,14 +1494,96 @@ __global__ __launch_bounds__(256) void k_map_apply(MapJob job)
         kcol = min(kcol, (uint32_t)__shfl_xor(kcol, off));
     }
     if ((threadIdx.x & 63) == 0) {
+        const int stripe = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMapStripes - 1);
         if (sat)
-            atomicAdd(&job.counters[kMapSaturatedReads], (unsigned long long)sat);
+            atomicAdd(&job.counters[kMapStripedSaturated + stripe], (unsigned long long)sat);
         if (updates)
-            atomicAdd(&job.counters[kMapUpdates], (unsigned long long)updates);
-        if (krow != 0xffffffffu) {
+            atomicAdd(&job.counters[kMapStripedUpdates + stripe], (unsigned long long)updates);
+        /* the minima only ever fall: skip the atomic when a (possibly stale) read already beats us */
+        if (krow != 0xffffffffu && (unsigned long long)krow < job.counters[kMapKnownRow])
             atomicMin(&job.counters[kMapKnownRow], (unsigned long long)krow);
+        if (kcol != 0xffffffffu && (unsigned long long)kcol < job.counters[kMapKnownCol])
             atomicMin(&job.counters[kMapKnownCol], (unsigned long long)kcol);
+    }
+}
+
+/* cells no ray ends in: their miss count through the miss table; clears the rest */
+__global__ __launch_bounds__(256) void k_map_apply(MapJob job)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid / job.pitch, col = gid - row * job.pitch;
+    uint32_t v = 0, sat = 0, updates = 0;
+    bool write = row < job.rows;
+    if (row < job.rows && col < job.cols) {
+        const int cell = row * job.cols + col;
+        if (job.n_hit[cell] == 0) {
+            updates = job.n_miss[cell];
+            v = map_iterate(job.lut_miss, 0, updates, sat);
+        } else {
+            write = false;                   /* k_map_apply_hits owns this cell */
         }
+    }
+    if (write)
+        job.cells[(size_t)row * job.pitch + col] = (uint16_t)v;
+    map_apply_totals(job, v, row, col, sat, updates);
+}
+
+/* Cells with hits: a chain of dependent table reads per cell (hit, a few
+ * misses, hit, ...), as long as the cell has hits and misses (a wall cell seen
+ * from 10 scans: ~100 + ~100). The longest chain's latency is the kernel's
+ * duration. So: the hit table sits in LDS (128 KB per workgroup); the miss
+ * counts are fetched four intervals at a time, one fetch ahead; and as few
+ * lanes of a wavefront as the cell count allows carry a cell, because a table
+ * gather costs per distinct cache line (64 cells per wave: ~340 ns per step,
+ * 4: ~100, 1: ~70). */
+__global__ __launch_bounds__(256) void k_map_apply_hits(MapJob job)
+{
+    extern __shared__ uint16_t hit_table[];
+    const uint32_t n_cells = (uint32_t)job.counters[kMapHitCells];
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t per_wave = min(max((n_cells + waves - 1u) / waves, 1u), 64u);
+    if (blockIdx.x * 4u * per_wave >= n_cells)
+        return;                              /* fewer cells than workgroups (uniform exit) */
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(job.lut_hit);
+        uint4* dst = reinterpret_cast<uint4*>(hit_table);
+        for (int i = threadIdx.x; i < 65536 * 2 / 16; i += 256)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    for (uint32_t first = 0; first < n_cells; first += waves * per_wave) {
+        const uint32_t idx = first + wave * per_wave + lane;
+        uint32_t v = 0, sat = 0, updates = 0;
+        int row = 0, col = 0;
+        if (lane < per_wave && idx < n_cells) {
+            const int cell = (int)job.hit_cells[idx];
+            row = cell / job.cols;
+            col = cell - row * job.cols;
+            const uint32_t n = job.n_hit[cell];
+            const uint4* between = reinterpret_cast<const uint4*>(job.lists + job.seg[cell] + map_between_offset(n));
+            uint4 cur = between[0];
+            for (uint32_t i0 = 0; i0 <= n; i0 += 4) {
+                const uint4 nxt = i0 + 4 <= n ? between[i0 / 4 + 1] : make_uint4(0, 0, 0, 0);
+                const uint32_t k4[4] = { cur.x, cur.y, cur.z, cur.w };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t i = i0 + j;
+                    if (i <= n) {
+                        updates += k4[j];
+                        v = map_iterate(job.lut_miss, v, k4[j], sat);
+                        if (i < n) {
+                            sat += v == 65535u;
+                            v = hit_table[v];
+                        }
+                    }
+                }
+                cur = nxt;
+            }
+            updates += n;
+            job.cells[(size_t)row * job.pitch + col] = (uint16_t)v;
+        }
+        map_apply_totals(job, v, row, col, sat, updates);
     }
 }
 
