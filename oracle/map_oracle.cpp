@@ -16,8 +16,14 @@
  *
  * PARITY STATUS: "parity unpinned" -- the reference has no fixtures for this
  * step and bresenham.cpp / grid_map.cpp include util.hpp (Eigen), so they
- * cannot be compiled here. The ray walk below is the reference's step-by-step
- * formulation; tests cross-check it against an independent closed form.
+ * cannot be compiled here. Pinned pieces: the conversions the cell update is
+ * made of (ProbabilityToValue, ProbabilityToOdds, OddsToProbability,
+ * ValueToOdds) are inline in grid_map_new/grid_values.hpp, which compiles from
+ * the reference tree as it lies; tests/test_cpu_map_oracle.py checks the bb_*
+ * functions below against them bit for bit (oracle/_ref and the committed
+ * tests/golden/ref_geometry.json), as it does for the pose algebra and the hit
+ * point. The ray walk is the reference's step-by-step formulation; tests
+ * cross-check it against an independent closed form.
  *
  * The dense array stands for GridMap<GridBinaryBayes>: unallocated blocks read
  * as 0 (unknown) and ConstructMapFromScans resets every kept block, so the
@@ -340,6 +346,13 @@ int orc_ray_cells(int sx, int sy, int ex, int ey, int scale, int* out, int cap)
     }
     return static_cast<int>(walk.size());
 }
+
+/* the conversions on their own, for the checks against the reference's inline
+ * primitives (oracle/_ref, tests/golden/ref_geometry.json) */
+unsigned orc_bb_probability_to_value(double prob) { return bb_probability_to_value(prob); }
+double orc_bb_probability_to_odds(double prob) { return bb_probability_to_odds(prob); }
+double orc_bb_odds_to_probability(double odds) { return bb_odds_to_probability(odds); }
+double orc_bb_value_to_odds(unsigned value) { return bb_value_to_odds(value, nullptr); }
 
 /* one cell update, for table checks: returns the new value */
 unsigned orc_bayes_update(unsigned value, double prob)

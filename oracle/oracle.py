@@ -66,6 +66,13 @@ def lib():
         _lib.orc_value_to_probability.restype = C.c_double
         _lib.orc_value_to_probability.argtypes = [C.c_uint]
         _lib.orc_score_at.restype = C.c_double
+        for name in ("orc_bb_probability_to_odds", "orc_bb_odds_to_probability"):
+            getattr(_lib, name).restype = C.c_double
+            getattr(_lib, name).argtypes = [C.c_double]
+        _lib.orc_bb_probability_to_value.restype = C.c_uint
+        _lib.orc_bb_probability_to_value.argtypes = [C.c_double]
+        _lib.orc_bb_value_to_odds.restype = C.c_double
+        _lib.orc_bb_value_to_odds.argtypes = [C.c_uint]
     return _lib
 
 
@@ -76,6 +83,14 @@ def ref():
         _ref = C.CDLL(REF_SO)
         _ref.ref_value_to_probability.restype = C.c_double
         _ref.ref_value_to_probability.argtypes = [C.c_uint]
+        if hasattr(_ref, "ref_value_to_odds"):
+            for name in ("ref_probability_to_odds", "ref_odds_to_probability"):
+                getattr(_ref, name).restype = C.c_double
+                getattr(_ref, name).argtypes = [C.c_double]
+            _ref.ref_probability_to_value.restype = C.c_uint
+            _ref.ref_probability_to_value.argtypes = [C.c_double]
+            _ref.ref_value_to_odds.restype = C.c_double
+            _ref.ref_value_to_odds.argtypes = [C.c_uint]
     return _ref
 
 

@@ -67,4 +67,20 @@ double ref_value_to_probability(unsigned value)
                               1e-3, 1.0 - 1e-3);
 }
 
+/* the inline primitives of grid_values.hpp:11-58 that the binary-Bayes cell
+ * update is made of, with the constants of grid_binary_bayes.hpp:163-176 */
+unsigned ref_probability_to_value(double prob)
+{
+    return ProbabilityToValue(prob, 1U, 65535U, 1e-3, 1.0 - 1e-3);
+}
+
+double ref_probability_to_odds(double prob) { return ProbabilityToOdds(prob); }
+
+double ref_odds_to_probability(double odds) { return OddsToProbability(odds); }
+
+double ref_value_to_odds(unsigned value)
+{
+    return ValueToOdds(static_cast<std::uint16_t>(value), 1U, 65535U, 1e-3, 1.0 - 1e-3);
+}
+
 } /* extern "C" */

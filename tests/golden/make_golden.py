@@ -70,6 +70,13 @@ def ref_geometry():
     vals = list(range(1, 65536, 257)) + [1, 2, 3, 32767, 32768, 65533, 65534]
     for v in sorted(set(vals)):
         out["value_to_probability"].append([v, hexd(ref.ref_value_to_probability(v))])
+    # the primitives of the binary-Bayes cell update (grid_values.hpp:11-58)
+    out["value_to_odds"] = [[v, hexd(ref.ref_value_to_odds(v))] for v in sorted(set(vals))]
+    probs = [1e-3, 1.0 - 1e-3, 0.46, 0.5, 0.62] + list(rng.uniform(1e-3, 1.0 - 1e-3, 200))
+    out["probability_to_value"] = [[hexd(p), int(ref.ref_probability_to_value(p))] for p in probs]
+    out["probability_to_odds"] = [[hexd(p), hexd(ref.ref_probability_to_odds(p))] for p in probs]
+    odds = [0.0, 1.0, 0.46 / 0.54, 0.62 / 0.38] + list(np.exp(rng.uniform(-8, 8, 200)))
+    out["odds_to_probability"] = [[hexd(o), hexd(ref.ref_odds_to_probability(o))] for o in odds]
     return out
 
 

@@ -1,11 +1,50 @@
 """CPU checks of the map-building restatement (oracle/map_oracle.cpp): the
 step-by-step ray walk against an independent closed form, the binary-Bayes cell
 update, and the resize geometry."""
+import json
 import math
+import os
+import struct
 
 import numpy as np
+import pytest
 
 from csm_hip import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def unhex(h):
+    return struct.unpack(">d", bytes.fromhex(h))[0]
+
+
+def test_bayes_primitives_bit_exact_vs_reference(oracle):
+    """The conversions the cell update is made of, against outputs of the
+    reference's own inline functions (grid_map_new/grid_values.hpp:11-58, built
+    into oracle/_ref; tests/golden/ref_geometry.json)."""
+    with open(os.path.join(GOLD, "ref_geometry.json")) as f:
+        gold = json.load(f)
+    lib = oracle.lib()
+    for v, h in gold["value_to_odds"]:
+        assert lib.orc_bb_value_to_odds(v) == unhex(h)
+    for h, v in gold["probability_to_value"]:
+        assert lib.orc_bb_probability_to_value(unhex(h)) == v
+    for h, o in gold["probability_to_odds"]:
+        assert lib.orc_bb_probability_to_odds(unhex(h)) == unhex(o)
+    for h, p in gold["odds_to_probability"]:
+        want = min(max(unhex(p), 1e-3), 1.0 - 1e-3)      # the wrapper's clamp, grid_binary_bayes.cpp:380
+        assert lib.orc_bb_odds_to_probability(unhex(h)) == want
+
+
+def test_bayes_primitives_against_live_reference_library(oracle):
+    ref = oracle.ref()
+    if ref is None or not hasattr(ref, "ref_value_to_odds"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    lib = oracle.lib()
+    for v in range(1, 65535):
+        assert lib.orc_bb_value_to_odds(v) == ref.ref_value_to_odds(v)
+    for p in np.linspace(1e-3, 1.0 - 1e-3, 20001):
+        assert lib.orc_bb_probability_to_value(float(p)) == ref.ref_probability_to_value(float(p))
 
 
 def closed_form_cells(sx, sy, ex, ey, s):
