@@ -338,6 +338,18 @@ int  csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* 
                                   int32_t n_nodes, const csm_map_builder_params* params,
                                   csm_map_build_info* info);
 
+/* The grid half of GridMapBuilder::UpdateGridMap
+ * (src/mapping/grid_map_builder.cpp:389-494): one new scan into the local map
+ * that is being built. The bounding box starts at the sensor position
+ * (ComputeBoundingBoxAndScanPointsMapLocal, :820-872); GridMap::Expand
+ * (grid_map.cpp:915-961) leaves the map alone if the box fits and otherwise
+ * resizes it to the union with its current extent, keeping the cells; then the
+ * same ray casts as above on top of the existing values. `map_id` must be
+ * resident (uploaded, or built by these calls) with the rows / cols of `shape`. */
+int  csm_update_map_with_scan(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
+                              const double global_map_pose[3], const csm_scan_node* node,
+                              const csm_map_builder_params* params, csm_map_build_info* info);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* enable = 1: every kernel launch is bracketed by HIP events on the ctx
  * stream; enable = 2: only the dominant (fine-level) scoring kernel, to keep

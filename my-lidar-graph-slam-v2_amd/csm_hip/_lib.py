@@ -159,6 +159,8 @@ SIGNATURES = {
                                         _P(GridSearchParams), _P(Summary)]),
     "csm_construct_map_from_scans": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
                                                C.c_int32, _P(MapBuilderParams), _P(MapBuildInfo)]),
+    "csm_update_map_with_scan": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
+                                           _P(MapBuilderParams), _P(MapBuildInfo)]),
     "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),
     "csm_kernel_time": (C.c_int, [_ctx, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "csm_reset_kernel_timing": (C.c_int, [_ctx]),

@@ -229,6 +229,19 @@ class Context:
         off_x, off_y, rows, cols, log2_block) of the map before the call; nodes =
         dicts(pose, angles, ranges, rel_pose, min_range, max_range). Returns
         (new shape dict, info dict); defaults as launcher_settings_default.json:183-186."""
+        return self._map_build(map_id, shape, map_pose, nodes, False, usable_range_min, usable_range_max,
+                               prob_hit, prob_miss, subpixel_scale)
+
+    def update_map_with_scan(self, map_id, shape, map_pose, node, usable_range_min=0.01,
+                             usable_range_max=20.0, prob_hit=0.62, prob_miss=0.46, subpixel_scale=100):
+        """The grid half of GridMapBuilder::UpdateGridMap
+        (src/my_lidar_graph_slam/mapping/grid_map_builder.cpp:389-494): one scan
+        node on top of the resident map `map_id`, which grows if it has to."""
+        return self._map_build(map_id, shape, map_pose, [node], True, usable_range_min, usable_range_max,
+                               prob_hit, prob_miss, subpixel_scale)
+
+    def _map_build(self, map_id, shape, map_pose, nodes, keep_cells, usable_range_min, usable_range_max,
+                   prob_hit, prob_miss, subpixel_scale):
         sh = L.MapShape(shape["res"], shape["off_x"], shape["off_y"], shape["rows"], shape["cols"],
                         shape["log2_block"])
         arr = (L.ScanNode * len(nodes))()
@@ -246,8 +259,12 @@ class Context:
         prm = L.MapBuilderParams(usable_range_min, usable_range_max, prob_hit, prob_miss, subpixel_scale)
         info = L.MapBuildInfo()
         mp = _f64(map_pose)
-        self._check(self.lib.csm_construct_map_from_scans(self._ctx, map_id, C.byref(sh), _ptr(mp), arr,
-                                                          len(nodes), C.byref(prm), C.byref(info)))
+        if keep_cells:
+            self._check(self.lib.csm_update_map_with_scan(self._ctx, map_id, C.byref(sh), _ptr(mp), arr,
+                                                          C.byref(prm), C.byref(info)))
+        else:
+            self._check(self.lib.csm_construct_map_from_scans(self._ctx, map_id, C.byref(sh), _ptr(mp), arr,
+                                                              len(nodes), C.byref(prm), C.byref(info)))
         self.shapes[map_id] = (sh.rows, sh.cols)
         new_shape = dict(res=sh.resolution, off_x=sh.offset_x, off_y=sh.offset_y, rows=sh.rows,
                          cols=sh.cols, log2_block=sh.log2_block_size)

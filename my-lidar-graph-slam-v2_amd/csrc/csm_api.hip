@@ -2195,16 +2195,27 @@ int map_index_to_block(int idx, int log2_block)
 
 } /* namespace */
 
-/* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:561-695) */
-int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
-                                 const double global_map_pose[3], const csm_scan_node* nodes,
-                                 int32_t n_nodes, const csm_map_builder_params* prm,
-                                 csm_map_build_info* info)
+/* Both map updates of GridMapBuilder. keep_cells = false: ConstructMapFromScans
+ * (src/mapping/grid_map_builder.cpp:561-695): resize to the scans' bounding box,
+ * reset, integrate. keep_cells = true: UpdateGridMap (:389-494): expand only if
+ * the scan does not fit, keep the cells, integrate one scan on top. */
+static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
+                     const double global_map_pose[3], const csm_scan_node* nodes,
+                     int32_t n_nodes, const csm_map_builder_params* prm,
+                     csm_map_build_info* info, bool keep_cells)
 {
     if (!ctx || !shape || !global_map_pose || !nodes || n_nodes < 1 || !prm ||
         !(shape->resolution > 0.0) || shape->log2_block_size < 0 || shape->log2_block_size > 12 ||
         prm->subpixel_scale < 1 || prm->subpixel_scale > 1024)
-        return fail(ctx, CSM_EINVAL, "csm_construct_map_from_scans: bad arguments");
+        return fail(ctx, CSM_EINVAL, "map build: bad arguments");
+    if (keep_cells) {
+        const DeviceGrid* have = find_grid(ctx, map_id);
+        if (!have || have->levels.empty())
+            return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
+        if (have->rows != shape->rows || have->cols != shape->cols)
+            return fail(ctx, CSM_EINVAL, "shape %d x %d does not match the resident map %d x %d",
+                        shape->rows, shape->cols, have->rows, have->cols);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto t0 = std::chrono::steady_clock::now();
     const int scale = prm->subpixel_scale;
@@ -2264,6 +2275,11 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     int box[4] = { 0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1 };
     double min_x = std::numeric_limits<double>::max(), min_y = min_x;
     double max_x = std::numeric_limits<double>::min(), max_y = max_x;   /* as the reference: smallest positive */
+    if (keep_cells) {
+        /* ComputeBoundingBoxAndScanPointsMapLocal starts from the sensor position (:835-841) */
+        min_x = max_x = table[0].x;
+        min_y = max_y = table[0].y;
+    }
     auto add_point = [&](double x, double y) {
         min_x = std::min(min_x, x);
         min_y = std::min(min_y, y);
@@ -2388,19 +2404,41 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
         box[3] = std::max(box[3], to_index(max_y + res, shape->offset_y));
     }
 
-    /* GridMap::Resize(BoundingBox<int>) (grid_map.cpp:841-889) on the CURRENT geometry */
+    /* GridMap::Resize(BoundingBox<int>) (grid_map.cpp:841-889) on the CURRENT geometry;
+     * for an update GridMap::Expand (grid_map.cpp:915-936) first: nothing changes if
+     * the box fits, else the box is joined with the current extent */
     const int lb = shape->log2_block_size, block = 1 << lb;
-    const int i_min_x = box[0], i_min_y = box[1], i_max_x = box[2] + 1, i_max_y = box[3] + 1;
-    const int b_min_x = map_index_to_block(i_min_x, lb), b_min_y = map_index_to_block(i_min_y, lb);
-    const int b_max_x = map_index_to_block(i_max_x + block - 1, lb);
-    const int b_max_y = map_index_to_block(i_max_y + block - 1, lb);
-    const long long rows_ll = (long long)(b_max_y - b_min_y) << lb, cols_ll = (long long)(b_max_x - b_min_x) << lb;
+    int i_min_x = box[0], i_min_y = box[1], i_max_x = box[2] + 1, i_max_y = box[3] + 1;
+    bool resized = true;
+    if (keep_cells) {
+        auto inside = [shape](int row, int col) {
+            return row >= 0 && row < shape->rows && col >= 0 && col < shape->cols;
+        };
+        if (inside(i_min_y, i_min_x) && inside(i_max_y - 1, i_max_x - 1)) {
+            resized = false;
+        } else {
+            i_min_x = std::min(0, i_min_x);
+            i_min_y = std::min(0, i_min_y);
+            i_max_x = std::max(shape->cols, i_max_x);
+            i_max_y = std::max(shape->rows, i_max_y);
+        }
+    }
+    int b_min_x = 0, b_min_y = 0;
+    long long rows_ll = shape->rows, cols_ll = shape->cols;
+    if (resized) {
+        b_min_x = map_index_to_block(i_min_x, lb);
+        b_min_y = map_index_to_block(i_min_y, lb);
+        const int b_max_x = map_index_to_block(i_max_x + block - 1, lb);
+        const int b_max_y = map_index_to_block(i_max_y + block - 1, lb);
+        rows_ll = (long long)(b_max_y - b_min_y) << lb;
+        cols_ll = (long long)(b_max_x - b_min_x) << lb;
+    }
     if (rows_ll < 1 || cols_ll < 1 || rows_ll * cols_ll > (1ll << 28))
         return fail(ctx, CSM_EINVAL, "resized map %lld x %lld is out of range", rows_ll, cols_ll);
     const int rows = (int)rows_ll, cols = (int)cols_ll;
     /* GridMapGeometry::Resize (grid_map_geometry.cpp:61-72) */
-    const double off_x = shape->offset_x + res * (b_min_x << lb);
-    const double off_y = shape->offset_y + res * (b_min_y << lb);
+    const double off_x = resized ? shape->offset_x + res * (b_min_x << lb) : shape->offset_x;
+    const double off_y = resized ? shape->offset_y + res * (b_min_y << lb) : shape->offset_y;
     for (MapNode& t : table) {
         t.sx = static_cast<int>(std::floor((t.x - off_x) / scaled_res));
         t.sy = static_cast<int>(std::floor((t.y - off_y) / scaled_res));
@@ -2434,7 +2472,25 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     DeviceGrid& g = ctx->grids[map_id];
     const int pitch = (cols + 7) & ~7;
     const size_t bytes = (size_t)rows * pitch * 2;
-    if (g.levels.empty() || !g.levels[0].owned || g.levels[0].cap < bytes) {
+    if (keep_cells && resized) {
+        /* GridMap::Resize moves the blocks (grid_map.cpp:866-879): the old cells, shifted */
+        Level base;
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc(reinterpret_cast<void**>(&base.cells), want) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", want);
+        base.win = 1;
+        base.owned = true;
+        base.cap = want;
+        const int shift_r = -(b_min_y << lb), shift_c = -(b_min_x << lb);
+        HIP_TRY(ctx, hipMemsetAsync(base.cells, 0, bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(base.cells + (size_t)shift_r * pitch + shift_c, (size_t)pitch * 2,
+                                      g.levels[0].cells, (size_t)g.pitch * 2, (size_t)g.cols * 2, g.rows,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (g.levels[0].owned)
+            (void)hipFree(g.levels[0].cells);
+        g.levels[0] = base;
+    } else if (!keep_cells && (g.levels.empty() || !g.levels[0].owned || g.levels[0].cap < bytes)) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         free_levels(g, false);
         Level base;
@@ -2484,6 +2540,7 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
     mj.lut_hit = d_lut;
     mj.lut_miss = d_lut + 65536;
     mj.cells = g.levels[0].cells;
+    mj.keep_cells = keep_cells ? 1 : 0;
     unsigned long long counters[kMapCounters] = { 0 };
     counters[kMapKnownRow] = counters[kMapKnownCol] = ~0ull;
     const auto t1 = std::chrono::steady_clock::now();
@@ -2530,7 +2587,7 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
         (void)hipEventDestroy(ev_b);
     }
     if (counters[kMapError]) {
-        free_levels(g, false);
+        free_levels(g, false);          /* the cells may be half updated: drop the map */
         ctx->grids.erase(map_id);
         return fail(ctx, CSM_EINVAL, "a ray leaves the resized map (flags %llu): the reference asserts",
                     counters[kMapError]);
@@ -2555,6 +2612,23 @@ int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* s
         info->device_us = dev_ms * 1e3;
     }
     return CSM_OK;
+}
+
+/* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:561-695) */
+int csm_construct_map_from_scans(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
+                                 const double global_map_pose[3], const csm_scan_node* nodes,
+                                 int32_t n_nodes, const csm_map_builder_params* prm,
+                                 csm_map_build_info* info)
+{
+    return map_build(ctx, map_id, shape, global_map_pose, nodes, n_nodes, prm, info, false);
+}
+
+/* the grid half of GridMapBuilder::UpdateGridMap (src/mapping/grid_map_builder.cpp:389-494) */
+int csm_update_map_with_scan(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
+                             const double global_map_pose[3], const csm_scan_node* node,
+                             const csm_map_builder_params* prm, csm_map_build_info* info)
+{
+    return map_build(ctx, map_id, shape, global_map_pose, node, node ? 1 : 0, prm, info, true);
 }
 
 /* ScanMatcherGridSearch::OptimizePose (scan_matcher_grid_search.cpp:69-190) */

@@ -297,6 +297,7 @@ struct MapJob {
     const uint16_t* lut_hit;   /* value -> value after one hit / miss update */
     const uint16_t* lut_miss;
     uint16_t* cells;           /* output grid, rows * pitch */
+    int32_t keep_cells;        /* 1: the updates go on top of the cells' values (UpdateGridMap) */
 };
 
 } /* namespace csm */

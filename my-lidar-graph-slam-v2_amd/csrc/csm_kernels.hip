@@ -1518,7 +1518,8 @@ __global__ __launch_bounds__(256) void k_map_apply(MapJob job)
         const int cell = row * job.cols + col;
         if (job.n_hit[cell] == 0) {
             updates = job.n_miss[cell];
-            v = map_iterate(job.lut_miss, 0, updates, sat);
+            const uint32_t start = job.keep_cells ? job.cells[(size_t)row * job.pitch + col] : 0u;
+            v = map_iterate(job.lut_miss, start, updates, sat);
         } else {
             write = false;                   /* k_map_apply_hits owns this cell */
         }
@@ -1561,6 +1562,8 @@ __global__ __launch_bounds__(256) void k_map_apply_hits(MapJob job)
             row = cell / job.cols;
             col = cell - row * job.cols;
             const uint32_t n = job.n_hit[cell];
+            if (job.keep_cells)
+                v = job.cells[(size_t)row * job.pitch + col];
             const uint4* between = reinterpret_cast<const uint4*>(job.lists + job.seg[cell] + map_between_offset(n));
             uint4 cur = between[0];
             for (uint32_t i0 = 0; i0 <= n; i0 += 4) {

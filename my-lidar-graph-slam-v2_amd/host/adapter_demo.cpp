@@ -59,6 +59,7 @@ static int run_builder(FILE* f, const int32_t* hdr)
     }
     GridMapBuilderHIP builder(matcher->Context(), prm[0], patch, nLatest, prm[1], prm[2], prm[3], prm[4]);
     builder.UpdateLatestMap(nodes);
+    const csm_map_build_info latestInfo = builder.LastBuildInfo();
     const GridMapView& map = builder.LatestMap();
     const std::vector<uint16_t> cells = builder.CopyLatestMapValues();
     uint64_t hash = 1469598103934665603ull;
@@ -68,14 +69,25 @@ static int run_builder(FILE* f, const int32_t* hdr)
     }
     ScanMatchingQuery q { map, nodes.back().mScanData, { init[0], init[1], init[2] } };
     const ScanMatchingSummary r = matcher->OptimizePose(q);
+    /* a local map grown scan by scan (UpdateGridMap), its pose = the first node's */
+    builder.CreateLocalMap(7);
+    for (const ScanNodeView& nd : nodes)
+        builder.UpdateGridMap(7, nodes.front().mGlobalPose, nd);
+    const GridMapView local = builder.LocalMap(7);
+    uint64_t localHash = 1469598103934665603ull;
+    for (uint16_t v : builder.CopyLocalMapValues(7)) {
+        localHash = (localHash ^ (v & 0xff)) * 1099511628211ull;
+        localHash = (localHash ^ (v >> 8)) * 1099511628211ull;
+    }
     std::printf("{\"rows\": %d, \"cols\": %d, \"off\": [\"%a\", \"%a\"], \"hash\": \"%016" PRIx64 "\", "
                 "\"rays\": %lld, \"updates\": %lld, \"map_pose\": [\"%a\", \"%a\", \"%a\"], "
-                "\"found\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\"}\n",
+                "\"found\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\", "
+                "\"local\": {\"rows\": %d, \"cols\": %d, \"off\": [\"%a\", \"%a\"], \"hash\": \"%016" PRIx64 "\"}}\n",
                 map.mRows, map.mCols, map.mPosOffsetX, map.mPosOffsetY, hash,
-                (long long)builder.LastBuildInfo().rays, (long long)builder.LastBuildInfo().cell_updates,
+                (long long)latestInfo.rays, (long long)latestInfo.cell_updates,
                 builder.LatestMapPose().mX, builder.LatestMapPose().mY, builder.LatestMapPose().mTheta,
                 r.mPoseFound ? 1 : 0, r.mEstimatedPose.mX, r.mEstimatedPose.mY, r.mEstimatedPose.mTheta,
-                r.mScoreValue);
+                r.mScoreValue, local.mRows, local.mCols, local.mPosOffsetX, local.mPosOffsetY, localHash);
     return 0;
 }
 

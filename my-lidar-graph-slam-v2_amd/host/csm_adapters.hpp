@@ -32,6 +32,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <set>
 #include <string>
@@ -536,6 +537,7 @@ public:
         const int desired = static_cast<int>(std::ceil(1.0 / mapResolution));
         const int cells = ((desired + block - 1) >> log2Block) << log2Block;
         this->mShape = { mapResolution, 0.0, 0.0, cells, cells, log2Block };
+        this->mInitialCells = cells;
         this->mLatestMap.mId = latestMapId;
         this->SyncView();
     }
@@ -587,6 +589,63 @@ public:
         return values;
     }
 
+    /* A new, empty local map on the device: GridMap(resolution, patchSize, 1.0, 1.0)
+     * as UpdatePoseGraph creates it (grid_map_builder.cpp:251) */
+    void CreateLocalMap(std::uint64_t localMapId)
+    {
+        csm_map_shape shape = this->mShape;
+        shape.offset_x = shape.offset_y = 0.0;
+        shape.rows = shape.cols = this->mInitialCells;
+        const std::vector<std::uint16_t> empty(static_cast<std::size_t>(shape.rows) * shape.cols, 0);
+        CSM_ASSERT_OK(this->mCtx, csm_upload_grid(this->mCtx, localMapId, empty.data(), shape.rows, shape.cols));
+        this->mLocalShapes[localMapId] = shape;
+    }
+
+    /* the grid half of GridMapBuilder::UpdateGridMap (grid_map_builder.cpp:389-494):
+     * the latest scan node into the local map that is being built */
+    void UpdateGridMap(std::uint64_t localMapId, const RobotPose2D<double>& globalMapPose,
+                       const ScanNodeView& latestScanNode)
+    {
+        auto it = this->mLocalShapes.find(localMapId);
+        if (it == this->mLocalShapes.end()) {
+            std::fprintf(stderr, "Assertion failed: local map %llu exists at %s:%d\n",
+                         static_cast<unsigned long long>(localMapId), __FILE__, __LINE__);
+            std::abort();
+        }
+        csm_scan_node flat {};
+        flat.global_pose[0] = latestScanNode.mGlobalPose.mX;
+        flat.global_pose[1] = latestScanNode.mGlobalPose.mY;
+        flat.global_pose[2] = latestScanNode.mGlobalPose.mTheta;
+        flat.scan = detail::ToScan(latestScanNode.mScanData);
+        flat.min_range = latestScanNode.mMinRange;
+        flat.max_range = latestScanNode.mMaxRange;
+        const double pose[3] = { globalMapPose.mX, globalMapPose.mY, globalMapPose.mTheta };
+        CSM_ASSERT_OK(this->mCtx, csm_update_map_with_scan(this->mCtx, localMapId, &it->second, pose, &flat,
+                                                           &this->mParams, &this->mInfo));
+    }
+
+    /* geometry + id of a local map (cells on the device), e.g. for a LoopDetectionQuery */
+    GridMapView LocalMap(std::uint64_t localMapId) const
+    {
+        const csm_map_shape& shape = this->mLocalShapes.at(localMapId);
+        GridMapView view;
+        view.mRows = shape.rows;
+        view.mCols = shape.cols;
+        view.mResolution = shape.resolution;
+        view.mPosOffsetX = shape.offset_x;
+        view.mPosOffsetY = shape.offset_y;
+        view.mId = localMapId;
+        return view;
+    }
+
+    std::vector<std::uint16_t> CopyLocalMapValues(std::uint64_t localMapId) const
+    {
+        const csm_map_shape& shape = this->mLocalShapes.at(localMapId);
+        std::vector<std::uint16_t> values(static_cast<std::size_t>(shape.rows) * shape.cols);
+        CSM_ASSERT_OK(this->mCtx, csm_download_level(this->mCtx, localMapId, 0, values.data()));
+        return values;
+    }
+
 private:
     void SyncView()
     {
@@ -604,6 +663,8 @@ private:
     csm_map_shape mShape {};
     csm_map_build_info mInfo {};
     GridMapView mLatestMap;
+    int mInitialCells = 0;
+    std::map<std::uint64_t, csm_map_shape> mLocalShapes;
 };
 
 } /* namespace CsmHip */

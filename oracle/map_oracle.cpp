@@ -270,15 +270,87 @@ int orc_map_resize(OrcMapShape* shape, const double mapPose[3], const OrcScanNod
  * shape. stats[0] = rays, [1] = cell updates, [2] = reads of table entry 65535
  * (out of bounds in the reference), [3] = rays whose end cell was not on the
  * walk (the reference asserts). Returns nonzero if an update leaves the map. */
+static int map_integrate(const OrcMapShape* shape, const double mapPose[3], const OrcScanNode* nodes,
+                         int nNodes, const OrcBuilderParams* prm, uint16_t* grid, long long* stats,
+                         bool reset);
+
 int orc_map_integrate(const OrcMapShape* shape, const double mapPose[3], const OrcScanNode* nodes,
                       int nNodes, const OrcBuilderParams* prm, uint16_t* grid, long long* stats)
+{
+    return map_integrate(shape, mapPose, nodes, nNodes, prm, grid, stats, true);
+}
+
+/* The update loop of GridMapBuilder::UpdateGridMap (grid_map_builder.cpp:446-477):
+ * the same ray casts onto the cells the local map already holds. */
+int orc_map_integrate_keep(const OrcMapShape* shape, const double mapPose[3], const OrcScanNode* node,
+                           const OrcBuilderParams* prm, uint16_t* grid, long long* stats)
+{
+    return map_integrate(shape, mapPose, node, 1, prm, grid, stats, false);
+}
+
+/* UpdateGridMap's bounding box + GridMap::Expand (grid_map_builder.cpp:425-434,
+ * 820-872; grid_map.cpp:915-961): the box starts at the sensor position, and
+ * the map is resized to the union with its current extent only if the box does
+ * not fit. `shape` is updated in place; *rowMin / *colMin = index of the new
+ * map's first cell in the old frame (0 when the map did not change). */
+int orc_map_expand(OrcMapShape* shape, const double mapPose[3], const OrcScanNode* node,
+                   const OrcBuilderParams* prm, int* rowMin, int* colMin)
+{
+    double gs[3], ls[3];
+    orc_compound(node->pose, node->rel, gs);
+    orc_inverse_compound(mapPose, gs, ls);
+    double minX = ls[0], minY = ls[1], maxX = ls[0], maxY = ls[1];
+    const double minRange = std::max(prm->usableMin, node->minRange);
+    const double maxRange = std::min(prm->usableMax, node->maxRange);
+    for (int i = 0; i < node->n; ++i) {
+        const double r = node->ranges[i];
+        if (r >= maxRange || r <= minRange)
+            continue;
+        double hp[2];
+        orc_hit_point(ls, r, node->angles[i], hp);
+        minX = std::min(minX, hp[0]);
+        minY = std::min(minY, hp[1]);
+        maxX = std::max(maxX, hp[0]);
+        maxY = std::max(maxY, hp[1]);
+    }
+    *rowMin = *colMin = 0;
+    if (!(minX < maxX) || !(minY < maxY))
+        return 2;                                   /* Assert in Expand(BoundingBox<double>) */
+    const int bx0 = position_to_index(minX - shape->res, shape->offX, shape->res);
+    const int by0 = position_to_index(minY - shape->res, shape->offY, shape->res);
+    const int bx1 = position_to_index(maxX + shape->res, shape->offX, shape->res) + 1;
+    const int by1 = position_to_index(maxY + shape->res, shape->offY, shape->res) + 1;
+    auto inside = [shape](int row, int col) {
+        return row >= 0 && row < shape->rows && col >= 0 && col < shape->cols;
+    };
+    if (inside(by0, bx0) && inside(by1 - 1, bx1 - 1))
+        return 0;
+    const int ux0 = std::min(0, bx0), uy0 = std::min(0, by0);
+    const int ux1 = std::max(shape->cols, bx1), uy1 = std::max(shape->rows, by1);
+    const int blockSize = 1 << shape->log2Block;
+    const int bMinX = index_to_block(ux0, shape->log2Block), bMinY = index_to_block(uy0, shape->log2Block);
+    const int bMaxX = index_to_block(ux1 + blockSize - 1, shape->log2Block);
+    const int bMaxY = index_to_block(uy1 + blockSize - 1, shape->log2Block);
+    *rowMin = bMinY << shape->log2Block;
+    *colMin = bMinX << shape->log2Block;
+    shape->rows = (bMaxY - bMinY) << shape->log2Block;
+    shape->cols = (bMaxX - bMinX) << shape->log2Block;
+    shape->offX += shape->res * *colMin;
+    shape->offY += shape->res * *rowMin;
+    return 0;
+}
+
+static int map_integrate(const OrcMapShape* shape, const double mapPose[3], const OrcScanNode* nodes,
+                         int nNodes, const OrcBuilderParams* prm, uint16_t* grid, long long* stats,
+                         bool reset)
 {
     const double oddsHit = bb_probability_to_odds(prm->probHit);     /* grid_map_builder.cpp:95-96 */
     const double oddsMiss = bb_probability_to_odds(prm->probMiss);
     const int scale = prm->subpixel;
     const double scaledRes = shape->res / scale;                     /* grid_map_geometry.cpp:46-58 */
     long long rays = 0, updates = 0, oob = 0, noEnd = 0;
-    std::memset(grid, 0, sizeof(uint16_t) * shape->rows * shape->cols);
+    if (reset)
+        std::memset(grid, 0, sizeof(uint16_t) * shape->rows * shape->cols);
     std::vector<Cell> walk;
     auto inside = [shape](int x, int y) {
         return x >= 0 && x < shape->cols && y >= 0 && y < shape->rows;

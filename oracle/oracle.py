@@ -319,6 +319,33 @@ def construct_map(shape, map_pose, nodes, usable_min=0.01, usable_max=20.0, prob
                                  end_missing=stats[3])
 
 
+def update_map(shape, grid, map_pose, node, usable_min=0.01, usable_max=20.0, prob_hit=0.62,
+               prob_miss=0.46, subpixel=100):
+    """Literal GridMapBuilder::UpdateGridMap for one scan node on a dense array:
+    Expand (keeping the cells), then the ray casts. Returns (new shape, new
+    grid, stats)."""
+    sh = MapShape(shape["res"], shape["off_x"], shape["off_y"], shape["rows"], shape["cols"],
+                  shape["log2_block"])
+    arr, keep = _nodes([node])
+    prm = BuilderParams(usable_min, usable_max, prob_hit, prob_miss, subpixel)
+    mp = _f64(map_pose)
+    r0, c0 = C.c_int(0), C.c_int(0)
+    rc = lib().orc_map_expand(C.byref(sh), _p(mp), arr, C.byref(prm), C.byref(r0), C.byref(c0))
+    if rc:
+        raise ValueError("orc_map_expand failed: %d" % rc)
+    old = np.ascontiguousarray(grid, dtype=np.uint16)
+    new = np.zeros((sh.rows, sh.cols), np.uint16)
+    new[-r0.value:-r0.value + old.shape[0], -c0.value:-c0.value + old.shape[1]] = old
+    stats = (C.c_longlong * 4)()
+    rc = lib().orc_map_integrate_keep(C.byref(sh), _p(mp), arr, C.byref(prm), _p(new), stats)
+    if rc:
+        raise ValueError("orc_map_integrate_keep failed: %d" % rc)
+    new_shape = dict(res=sh.res, off_x=sh.offX, off_y=sh.offY, rows=sh.rows, cols=sh.cols,
+                     log2_block=sh.log2Block)
+    return new_shape, new, dict(rays=stats[0], updates=stats[1], oob_reads=stats[2],
+                                end_missing=stats[3], row_min=r0.value, col_min=c0.value)
+
+
 def ray_cells(sx, sy, ex, ey, scale=100, cap=1 << 16):
     out = np.zeros(2 * cap, np.int32)
     n = lib().orc_ray_cells(sx, sy, ex, ey, scale, _p(out), cap)

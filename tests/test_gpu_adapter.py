@@ -146,3 +146,14 @@ def test_cpp_grid_map_builder_adapter(tmp_path, oracle):
     assert got["found"] == want["found"] == 1
     assert [float.fromhex(v) for v in got["pose"]] == want["estimatedPose"]
     assert float.fromhex(got["score"]) == want["scoreMax"]
+    # the local map grown scan by scan (CreateLocalMap + UpdateGridMap)
+    shape = case["shape"]
+    grid = np.zeros((shape["rows"], shape["cols"]), np.uint16)
+    for nd in nodes:
+        shape, grid, _ = oracle.update_map(shape, grid, nodes[0]["pose"], nd)
+    assert (got["local"]["rows"], got["local"]["cols"]) == (shape["rows"], shape["cols"])
+    assert [float.fromhex(v) for v in got["local"]["off"]] == [shape["off_x"], shape["off_y"]]
+    h = 1469598103934665603
+    for b in grid.astype("<u2").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert got["local"]["hash"] == "%016x" % h

@@ -183,3 +183,72 @@ def test_map_degenerate_boxes(gpu_ctx, oracle):
     two["nodes"] = [node, dict(node, pose=(0.3, 0.7, 0.0))]              # a second sensor position opens it
     _check(gpu_ctx, oracle, two, 460)
     gpu_ctx.release_grid(460)
+
+
+def _check_update(gpu_ctx, oracle, map_id, shape, grid, map_pose, node, **kw):
+    okw = {{"usable_range_max": "usable_max", "usable_range_min": "usable_min", "prob_hit": "prob_hit",
+            "prob_miss": "prob_miss", "subpixel_scale": "subpixel"}[k]: v for k, v in kw.items()}
+    want_shape, want_grid, stats = oracle.update_map(shape, grid, map_pose, node, **okw)
+    got_shape, info = gpu_ctx.update_map_with_scan(map_id, shape, map_pose, node, **kw)
+    assert got_shape == want_shape
+    got = gpu_ctx.download_level(map_id, 0)
+    bad = np.argwhere(got != want_grid)
+    assert bad.size == 0, (len(bad), bad[:5])
+    assert (info["rays"], info["cell_updates"], info["saturated_reads"]) == \
+        (stats["rays"], stats["updates"], stats["oob_reads"])
+    ys, xs = np.nonzero(want_grid)
+    first = (ys.min(), xs.min()) if ys.size else want_grid.shape
+    assert (info["first_known_row"], info["first_known_col"]) == first
+    return want_shape, want_grid, stats
+
+
+@pytest.mark.parametrize("seed,n_beams", [(0, 360), (1, 1080), (2, 181)])
+def test_local_map_grows_scan_by_scan(gpu_ctx, oracle, seed, n_beams):
+    """GridMapBuilder::UpdateGridMap: a fresh 1 m x 1 m local map takes one scan
+    after the other; it expands when a scan does not fit and keeps its cells."""
+    case = synth.map_case(seed, n_scans=8, n_beams=n_beams, step=0.4,
+                          rel_pose=(0.08, 0.0, 0.0) if seed else (0.0, 0.0, 0.0))
+    shape = case["shape"]
+    grid = np.zeros((shape["rows"], shape["cols"]), np.uint16)
+    gpu_ctx.upload_grid(500 + seed, grid)
+    grew = 0
+    for nd in case["nodes"]:
+        shape, grid, stats = _check_update(gpu_ctx, oracle, 500 + seed, shape, grid, case["map_pose"], nd,
+                                           usable_range_max=6.0)
+        grew += (stats["row_min"], stats["col_min"]) != (0, 0) or False
+    assert grew >= 1
+    # the finished local map serves the loop detector without an upload
+    geom = (shape["res"], shape["off_x"], shape["off_y"])
+    nd = case["nodes"][3]
+    mp = case["map_pose"]
+    c, s_ = math.cos(mp[2]), math.sin(mp[2])
+    dx, dy = nd["pose"][0] + 0.2 - mp[0], nd["pose"][1] - 0.15 - mp[1]
+    init = (c * dx + s_ * dy, -s_ * dx + c * dy, nd["pose"][2] + 0.03 - mp[2])
+    q = dict(map_id=500 + seed, geom=geom, angles=nd["angles"], ranges=nd["ranges"], rel_pose=nd["rel_pose"],
+             init_pose=init)
+    out = gpu_ctx.bnb_match_batch([q], 1.5, 1.5, 0.3, 2, 0.3, 0.5)[0]
+    want = oracle.bnb(dict(grid=grid, geom=geom, angles=nd["angles"], ranges=nd["ranges"],
+                           rel_pose=nd["rel_pose"], init_pose=init), 1.5, 1.5, 0.3, 2, 0.3, 0.5)
+    assert out["pose_found"] == want["found"]
+    if want["found"]:
+        assert list(out["estimated_pose"]) == want["estimatedPose"]
+        assert out["raw"]["score"] == want["scoreMax"]
+    gpu_ctx.release_grid(500 + seed)
+
+
+def test_update_onto_uploaded_map_and_errors(gpu_ctx, oracle):
+    """An uploaded (host-built) map as the starting point; growth towards
+    negative indices; shape mismatch and missing map are refused."""
+    case = synth.map_case(9, n_scans=4, n_beams=360)
+    shape, grid, _ = oracle.construct_map(case["shape"], case["map_pose"], case["nodes"][:2])
+    gpu_ctx.upload_grid(510, grid)
+    far = dict(case["nodes"][3], pose=(case["nodes"][3]["pose"][0] - 6.0, case["nodes"][3]["pose"][1] - 5.0,
+                                       case["nodes"][3]["pose"][2]))
+    shape2, grid2, stats = _check_update(gpu_ctx, oracle, 510, shape, grid, case["map_pose"], far)
+    assert stats["row_min"] < 0 or stats["col_min"] < 0
+    _check_update(gpu_ctx, oracle, 510, shape2, grid2, case["map_pose"], case["nodes"][2])
+    with pytest.raises(api.CsmError):
+        gpu_ctx.update_map_with_scan(510, shape, case["map_pose"], case["nodes"][2])     # stale shape
+    with pytest.raises(api.CsmError):
+        gpu_ctx.update_map_with_scan(511, shape2, case["map_pose"], case["nodes"][2])    # not resident
+    gpu_ctx.release_grid(510)
