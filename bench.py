@@ -325,11 +325,21 @@ def main():
 
     wl = make_workload(rank, SCANS_PER_STEP)
     rx, ry, rt, L = wl["params"]
-    ctx = api.Context(dev_index)
+    # The scans of a step are independent: they alternate between N_STREAMS
+    # matcher contexts (one HIP stream each), so one scan's small kernels (bin,
+    # arg-max, finalize: a few workgroups each) run beside another scan's
+    # full-chip scoring kernel instead of leaving the chip idle.
+    n_streams = max(1, min(SCANS_PER_STEP, int(os.environ.get("CSM_BENCH_STREAMS", "2"))))
     stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.upload_grid(1, wl["grid"])
-    ctx.build_pyramid(1, [1, L])
+    side_streams = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    ctxs = []
+    for k in range(n_streams):
+        c = api.Context(dev_index)
+        c.set_stream((stream if k == 0 else side_streams[k - 1]).cuda_stream)
+        c.upload_grid(1, wl["grid"])
+        c.build_pyramid(1, [1, L])
+        ctxs.append(c)
+    ctx = ctxs[0]
 
     n_beams = 1080
     windows, cols, rows_ = [], [], []
@@ -348,9 +358,13 @@ def main():
     gathered = torch.zeros(world * SCANS_PER_STEP * rec_bytes, dtype=torch.uint8, device=dev)
 
     def step():
+        for s2 in side_streams:
+            s2.wait_stream(stream)           # the previous step's all-gather has read `results`
         for i in range(SCANS_PER_STEP):
-            ctx.score_window_dev(1, windows[i], cols[i].data_ptr(), rows_[i].data_ptr(),
-                                 results.data_ptr() + i * rec_bytes)
+            ctxs[i % n_streams].score_window_dev(1, windows[i], cols[i].data_ptr(), rows_[i].data_ptr(),
+                                                 results.data_ptr() + i * rec_bytes)
+        for s2 in side_streams:
+            stream.wait_stream(s2)
         if world > 1:
             if rehearse:
                 host = results.cpu()
@@ -370,24 +384,35 @@ def main():
     fence()
     # events around the dominant kernel only inside the timed region; the
     # other kernels are timed in a short extra pass afterwards
-    ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
-    ctx.reset_kernel_timing()
+    for c in ctxs:
+        c.lib.csm_enable_kernel_timing(c._ctx, 2)
+        c.reset_kernel_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    ctx.enable_kernel_timing(False)
-    fine_ms, fine_n = ctx.kernel_time("score_fine")
-    ctx.lib.csm_enable_kernel_timing(ctx._ctx, 1)
-    ctx.reset_kernel_timing()
+
+    def timer_sum(name):
+        ms = n = 0
+        for c in ctxs:
+            a, b = c.kernel_time(name)
+            ms, n = ms + a, n + b
+        return ms, n
+    for c in ctxs:
+        c.enable_kernel_timing(False)
+    fine_ms, fine_n = timer_sum("score_fine")
+    for c in ctxs:
+        c.lib.csm_enable_kernel_timing(c._ctx, 1)
+        c.reset_kernel_timing()
     step()
     fence()
-    ctx.enable_kernel_timing(False)
-    coarse_ms, coarse_n = ctx.kernel_time("score_coarse")
-    bin_ms, bin_n = ctx.kernel_time("bin")
-    fin_ms, fin_n = ctx.kernel_time("finalize")
-    arg_ms, arg_n = ctx.kernel_time("argmax")
+    for c in ctxs:
+        c.enable_kernel_timing(False)
+    coarse_ms, coarse_n = timer_sum("score_coarse")
+    bin_ms, bin_n = timer_sum("bin")
+    fin_ms, fin_n = timer_sum("finalize")
+    arg_ms, arg_n = timer_sum("argmax")
 
     # extra (not `value`): the same scans through the batched detector entry
     # (csm_correlative_match_batch: scans arrive as host arrays, projection on
@@ -453,6 +478,7 @@ def main():
                 "workload": "configs[1]: frontend CSM, 1080-beam scan, 400x400@5cm grid, "
                             "+-2 m/+-30 deg window at 5 cm/0.5 deg, L=4",
                 "scans_per_step": SCANS_PER_STEP,
+                "streams": n_streams,
                 "candidates_per_scan": cands_per_launch,
                 "beams": n_beams,
                 "parallelism": "scans sharded per GPU, all-gather of 48-B best records" if world > 1
@@ -483,7 +509,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
