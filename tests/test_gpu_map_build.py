@@ -252,3 +252,12 @@ def test_update_onto_uploaded_map_and_errors(gpu_ctx, oracle):
     with pytest.raises(api.CsmError):
         gpu_ctx.update_map_with_scan(511, shape2, case["map_pose"], case["nodes"][2])    # not resident
     gpu_ctx.release_grid(510)
+
+
+def test_map_many_scans_fine_resolution(gpu_ctx, oracle):
+    """60 scans x 1080 beams at 2.5 cm (65k rays, windows larger than the LDS
+    budget, cells with hundreds of hits)."""
+    case = synth.map_case(40, n_scans=60, n_beams=1080, res=0.025, max_range=12.0, step=0.05)
+    shape, grid, info = _check(gpu_ctx, oracle, case, 470)
+    assert info["rays"] > 60000 and info["cell_updates"] > 4e6
+    gpu_ctx.release_grid(470)
