@@ -326,6 +326,16 @@ typedef struct {
     double  device_us;          /* upload + kernels of the update */
 } csm_map_build_info;
 
+/* Host only. GridMap<T>::Resize(BoundingBox<int>) (src/grid_map_new/grid_map.cpp:841-889)
+ * on `shape`: box = { min col, min row, max col, max row } (inclusive cell
+ * indices in the map's current frame), blocks per IndexToBlock (:804-814),
+ * offsets per GridMapGeometry::Resize (grid_map_geometry.cpp:61-72). With
+ * expand != 0 GridMap<T>::Expand (:915-936) runs first: nothing changes if the
+ * box fits, else it is joined with the current extent. shift_out (may be null)
+ * = first row, first column of the new map in the old frame. */
+int  csm_host_map_resize(csm_map_shape* shape, const int32_t box[4], int32_t expand,
+                         int32_t shift_out[2]);
+
 /* GridMapBuilder::ConstructMapFromScans (src/mapping/grid_map_builder.cpp:561-695)
  * = UpdateLatestMap's work (:497-527): bounding box of the sensor positions and
  * usable hit points, GridMap::Resize + ResetValues, then a sub-pixel ray cast

@@ -159,6 +159,7 @@ SIGNATURES = {
                                         _P(GridSearchParams), _P(Summary)]),
     "csm_construct_map_from_scans": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
                                                C.c_int32, _P(MapBuilderParams), _P(MapBuildInfo)]),
+    "csm_host_map_resize": (C.c_int, [_P(MapShape), C.c_void_p, C.c_int32, C.c_void_p]),
     "csm_update_map_with_scan": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
                                            _P(MapBuilderParams), _P(MapBuildInfo)]),
     "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),

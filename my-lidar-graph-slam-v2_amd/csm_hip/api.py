@@ -57,6 +57,20 @@ def host_search_step(resolution, ranges):
     return sx.value, sy.value, st.value
 
 
+def host_map_resize(shape, box, expand=False):
+    """GridMap::Resize / Expand on an index box (min col, min row, max col, max
+    row; inclusive). Returns (new shape dict, (first row, first col) in the old frame)."""
+    sh = L.MapShape(shape["res"], shape["off_x"], shape["off_y"], shape["rows"], shape["cols"],
+                    shape["log2_block"])
+    b = np.ascontiguousarray(box, dtype=np.int32)
+    shift = np.zeros(2, np.int32)
+    rc = L.load().csm_host_map_resize(C.byref(sh), _ptr(b), 1 if expand else 0, _ptr(shift))
+    if rc:
+        raise CsmError(rc, "csm_host_map_resize")
+    return (dict(res=sh.resolution, off_x=sh.offset_x, off_y=sh.offset_y, rows=sh.rows, cols=sh.cols,
+                 log2_block=sh.log2_block_size), (int(shift[0]), int(shift[1])))
+
+
 def host_window(rng, step):
     return L.load().csm_host_window(rng, step)
 

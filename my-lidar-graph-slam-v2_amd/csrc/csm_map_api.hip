@@ -54,6 +54,50 @@ int map_index_to_block(int idx, int log2_block)
 
 } /* namespace */
 
+/* GridMap<T>::Resize(BoundingBox<int>) (src/grid_map_new/grid_map.cpp:841-889) and, with
+ * expand != 0, GridMap<T>::Expand (:915-936) in front of it, on index boxes: host only. */
+int csm_host_map_resize(csm_map_shape* shape, const int32_t box[4], int32_t expand, int32_t shift_out[2])
+{
+    if (!shape || !box || shape->log2_block_size < 0 || shape->log2_block_size > 12 ||
+        !(shape->resolution > 0.0))
+        return CSM_EINVAL;
+    const int lb = shape->log2_block_size, block = 1 << lb;
+    long long i_min_x = box[0], i_min_y = box[1], i_max_x = (long long)box[2] + 1, i_max_y = (long long)box[3] + 1;
+    if (shift_out)
+        shift_out[0] = shift_out[1] = 0;
+    if (i_min_x >= i_max_x || i_min_y >= i_max_y)
+        return CSM_EINVAL;                  /* the reference asserts */
+    if (expand) {
+        auto inside = [shape](long long row, long long col) {
+            return row >= 0 && row < shape->rows && col >= 0 && col < shape->cols;
+        };
+        if (inside(i_min_y, i_min_x) && inside(i_max_y - 1, i_max_x - 1))
+            return CSM_OK;                  /* the box fits: nothing changes */
+        i_min_x = std::min(0ll, i_min_x);
+        i_min_y = std::min(0ll, i_min_y);
+        i_max_x = std::max((long long)shape->cols, i_max_x);
+        i_max_y = std::max((long long)shape->rows, i_max_y);
+    }
+    if (i_min_x < -(1ll << 30) || i_min_y < -(1ll << 30) || i_max_x > (1ll << 30) || i_max_y > (1ll << 30))
+        return CSM_EINVAL;
+    const int b_min_x = map_index_to_block((int)i_min_x, lb), b_min_y = map_index_to_block((int)i_min_y, lb);
+    const int b_max_x = map_index_to_block((int)i_max_x + block - 1, lb);
+    const int b_max_y = map_index_to_block((int)i_max_y + block - 1, lb);
+    const long long rows = (long long)(b_max_y - b_min_y) << lb, cols = (long long)(b_max_x - b_min_x) << lb;
+    if (rows < 1 || cols < 1 || rows * cols > (1ll << 28))
+        return CSM_EINVAL;
+    shape->rows = (int32_t)rows;
+    shape->cols = (int32_t)cols;
+    /* GridMapGeometry::Resize (src/grid_map_new/grid_map_geometry.cpp:61-72) */
+    shape->offset_x += shape->resolution * (b_min_x << lb);
+    shape->offset_y += shape->resolution * (b_min_y << lb);
+    if (shift_out) {
+        shift_out[0] = b_min_y << lb;
+        shift_out[1] = b_min_x << lb;
+    }
+    return CSM_OK;
+}
+
 /* Both map updates of GridMapBuilder. keep_cells = false: ConstructMapFromScans
  * (src/mapping/grid_map_builder.cpp:561-695): resize to the scans' bounding box,
  * reset, integrate. keep_cells = true: UpdateGridMap (:389-494): expand only if
@@ -263,41 +307,17 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
         box[3] = std::max(box[3], to_index(max_y + res, shape->offset_y));
     }
 
-    /* GridMap::Resize(BoundingBox<int>) (grid_map.cpp:841-889) on the CURRENT geometry;
-     * for an update GridMap::Expand (grid_map.cpp:915-936) first: nothing changes if
-     * the box fits, else the box is joined with the current extent */
-    const int lb = shape->log2_block_size, block = 1 << lb;
-    int i_min_x = box[0], i_min_y = box[1], i_max_x = box[2] + 1, i_max_y = box[3] + 1;
-    bool resized = true;
-    if (keep_cells) {
-        auto inside = [shape](int row, int col) {
-            return row >= 0 && row < shape->rows && col >= 0 && col < shape->cols;
-        };
-        if (inside(i_min_y, i_min_x) && inside(i_max_y - 1, i_max_x - 1)) {
-            resized = false;
-        } else {
-            i_min_x = std::min(0, i_min_x);
-            i_min_y = std::min(0, i_min_y);
-            i_max_x = std::max(shape->cols, i_max_x);
-            i_max_y = std::max(shape->rows, i_max_y);
-        }
-    }
-    int b_min_x = 0, b_min_y = 0;
-    long long rows_ll = shape->rows, cols_ll = shape->cols;
-    if (resized) {
-        b_min_x = map_index_to_block(i_min_x, lb);
-        b_min_y = map_index_to_block(i_min_y, lb);
-        const int b_max_x = map_index_to_block(i_max_x + block - 1, lb);
-        const int b_max_y = map_index_to_block(i_max_y + block - 1, lb);
-        rows_ll = (long long)(b_max_y - b_min_y) << lb;
-        cols_ll = (long long)(b_max_x - b_min_x) << lb;
-    }
-    if (rows_ll < 1 || cols_ll < 1 || rows_ll * cols_ll > (1ll << 28))
-        return fail(ctx, CSM_EINVAL, "resized map %lld x %lld is out of range", rows_ll, cols_ll);
-    const int rows = (int)rows_ll, cols = (int)cols_ll;
-    /* GridMapGeometry::Resize (grid_map_geometry.cpp:61-72) */
-    const double off_x = resized ? shape->offset_x + res * (b_min_x << lb) : shape->offset_x;
-    const double off_y = resized ? shape->offset_y + res * (b_min_y << lb) : shape->offset_y;
+    /* GridMap::Resize(BoundingBox<int>) / GridMap::Expand on the CURRENT geometry */
+    csm_map_shape next = *shape;
+    int32_t shift[2] = { 0, 0 };            /* first row / column of the new map in the old frame */
+    if (csm_host_map_resize(&next, box, keep_cells ? 1 : 0, shift) != CSM_OK)
+        return fail(ctx, CSM_EINVAL, "resized map is out of range");
+    const bool resized = !keep_cells || shift[0] != 0 || shift[1] != 0 || next.rows != shape->rows ||
+                         next.cols != shape->cols;
+    const int lb = shape->log2_block_size;
+    const int b_min_y = shift[0] >> lb, b_min_x = shift[1] >> lb;     /* exact: multiples of the block */
+    const int rows = next.rows, cols = next.cols;
+    const double off_x = next.offset_x, off_y = next.offset_y;
     for (MapNode& t : table) {
         t.sx = static_cast<int>(std::floor((t.x - off_x) / scaled_res));
         t.sy = static_cast<int>(std::floor((t.y - off_y) / scaled_res));

@@ -13,6 +13,9 @@ csm_cases.json     Outputs of the CPU oracle (oracle/csm_oracle.cpp) on seeded
                    expected answers for the HIP path on the GPU box. They are
                    NOT reference outputs (the reference matcher cannot be built
                    here: it needs Eigen3 and Boost).
+map_cases.json     Outputs of the CPU oracle (oracle/map_oracle.cpp) for map builds:
+                   geometry, FNV-1a hash of the cells, update counters. Same status
+                   as csm_cases.json.
 Fixtures are data only: inputs are regenerated from seeds by csm_hip/synth.py.
 """
 import json
@@ -127,7 +130,48 @@ def csm_cases():
     return out
 
 
+MAP_CASES = [
+    # name, synth.map_case kwargs, builder kwargs (oracle names)
+    ("latest_10x360", dict(seed=0, n_scans=10, n_beams=360), {}),
+    ("latest_10x1080", dict(seed=2, n_scans=10, n_beams=1080), {}),
+    ("offset_sensor_noise", dict(seed=3, n_scans=6, n_beams=500, rel_pose=[0.1, -0.05, 0.02], noise=0.01),
+     dict(usable_max=4.0, prob_hit=0.7, prob_miss=0.4, subpixel=10)),
+]
+
+
+def fnv64(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a, dtype="<u2").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def map_cases():
+    """Map builds (oracle/map_oracle.cpp): the batch build of all scans, then the
+    same scans one by one into a fresh local map."""
+    out = []
+    for name, kw, bkw in MAP_CASES:
+        skw = dict(kw)
+        if "rel_pose" in skw:
+            skw["rel_pose"] = tuple(skw["rel_pose"])
+        case = synth.map_case(**skw)
+        shape, grid, stats = O.construct_map(case["shape"], case["map_pose"], case["nodes"], **bkw)
+        inc_shape = case["shape"]
+        inc = np.zeros((inc_shape["rows"], inc_shape["cols"]), np.uint16)
+        for nd in case["nodes"]:
+            inc_shape, inc, _ = O.update_map(inc_shape, inc, case["map_pose"], nd, **bkw)
+        out.append({"name": name, "synth": kw, "builder": bkw,
+                    "batch": {"rows": shape["rows"], "cols": shape["cols"], "off": [hexd(shape["off_x"]), hexd(shape["off_y"])],
+                              "hash": fnv64(grid), "rays": stats["rays"], "updates": stats["updates"],
+                              "saturated": stats["oob_reads"]},
+                    "incremental": {"rows": inc_shape["rows"], "cols": inc_shape["cols"],
+                                    "off": [hexd(inc_shape["off_x"]), hexd(inc_shape["off_y"])], "hash": fnv64(inc)}})
+    return out
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "map_cases.json"), "w") as f:
+        json.dump(map_cases(), f, indent=1)
     with open(os.path.join(HERE, "ref_geometry.json"), "w") as f:
         json.dump(ref_geometry(), f)
     with open(os.path.join(HERE, "csm_cases.json"), "w") as f:

@@ -76,3 +76,42 @@ def test_projection_matches_oracle_bit_for_bit(oracle):
         assert np.array_equal(col[t + wt], c)
         assert np.array_equal(row[t + wt], r)
     assert np.array_equal(rc[wt], case["ranges"] * np.cos(sensor[2] + case["angles"]))
+
+
+def test_host_map_resize_matches_oracle():
+    """csm_host_map_resize (GridMap::Resize / Expand on index boxes) against the
+    CPU restatement, over frames with negative indices and odd block sizes."""
+    import math
+    from oracle import oracle
+    from csm_hip import api
+    rng = np.random.RandomState(5)
+    for _ in range(300):
+        res = float(rng.choice([0.05, 0.1, 0.025]))
+        lb = int(rng.choice([2, 4, 5]))
+        shape = dict(res=res, off_x=float(rng.uniform(-5, 5)), off_y=float(rng.uniform(-5, 5)),
+                     rows=(1 << lb) * int(rng.randint(1, 9)), cols=(1 << lb) * int(rng.randint(1, 9)),
+                     log2_block=lb)
+        # two sensor positions are the only points: their box drives the resize
+        pts = rng.uniform(-8, 8, (2, 2))
+        nodes = [dict(pose=(float(p[0]), float(p[1]), 0.0), angles=np.zeros(1), ranges=np.zeros(1),
+                      min_range=1.0, max_range=2.0) for p in pts]
+        try:
+            want, _, _ = oracle.construct_map(shape, (0.0, 0.0, 0.0), nodes)
+        except ValueError:
+            continue
+        tiny = np.finfo(np.float64).tiny                     # the reference's initial maximum
+        xs, ys = list(pts[:, 0]), list(pts[:, 1])
+        box = [math.floor((min(xs) - res - shape["off_x"]) / res), math.floor((min(ys) - res - shape["off_y"]) / res),
+               math.floor((max(xs + [tiny]) + res - shape["off_x"]) / res),
+               math.floor((max(ys + [tiny]) + res - shape["off_y"]) / res)]
+        got, shift = api.host_map_resize(shape, box)
+        assert got == want
+        assert shift[0] % (1 << lb) == 0 and shift[1] % (1 << lb) == 0
+        # Expand: a box inside the map changes nothing, one outside joins the extent
+        same, shift0 = api.host_map_resize(got, [1, 1, got["cols"] - 2, got["rows"] - 2], expand=True)
+        assert same == got and shift0 == (0, 0)
+        grown, sh1 = api.host_map_resize(got, [-3, 2, 5, got["rows"] + 1], expand=True)
+        assert grown["cols"] >= got["cols"] + (1 << lb) and grown["rows"] >= got["rows"] + (1 << lb)
+        assert sh1[1] < 0 and sh1[0] == 0
+    with pytest.raises(api.CsmError):
+        api.host_map_resize(shape, [5, 5, 4, 9])             # empty box: the reference asserts

@@ -167,3 +167,26 @@ def test_construct_map_respects_usable_range(oracle):
     _, _, full = oracle.construct_map(case["shape"], case["map_pose"], case["nodes"])
     _, _, short = oracle.construct_map(case["shape"], case["map_pose"], case["nodes"], usable_max=2.0)
     assert 0 < short["rays"] < full["rays"]
+
+
+def _map_cases():
+    with open(os.path.join(GOLD, "map_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("rec", _map_cases(), ids=lambda r: r["name"])
+def test_map_golden(oracle, rec):
+    """Regression pin of the restatement (tests/golden/map_cases.json)."""
+    kw = dict(rec["synth"])
+    if "rel_pose" in kw:
+        kw["rel_pose"] = tuple(kw["rel_pose"])
+    case = synth.map_case(**kw)
+    shape, grid, stats = oracle.construct_map(case["shape"], case["map_pose"], case["nodes"], **rec["builder"])
+    h = 1469598103934665603
+    for b in grid.astype("<u2").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    want = rec["batch"]
+    assert "%016x" % h == want["hash"]
+    assert (shape["rows"], shape["cols"], stats["rays"], stats["updates"], stats["oob_reads"]) == \
+        (want["rows"], want["cols"], want["rays"], want["updates"], want["saturated"])
+    assert [shape["off_x"], shape["off_y"]] == [unhex(v) for v in want["off"]]

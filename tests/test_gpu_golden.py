@@ -85,3 +85,46 @@ def test_config2_full_size_properties(gpu_ctx, oracle):
     # function of the absolute best pose only
     assert a["raw"]["key"] == 32268 * a["raw"]["known"] + 499 * a["raw"]["sum_values"]
     gpu_ctx.release_grid(77)
+
+
+def _map_cases():
+    with open(os.path.join(GOLD, "map_cases.json")) as f:
+        return json.load(f)
+
+
+def _fnv64(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a, dtype="<u2").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+_BUILDER_NAMES = {"usable_max": "usable_range_max", "usable_min": "usable_range_min", "prob_hit": "prob_hit",
+                  "prob_miss": "prob_miss", "subpixel": "subpixel_scale"}
+
+
+@pytest.mark.parametrize("rec", _map_cases(), ids=lambda r: r["name"])
+def test_map_fixture(gpu_ctx, rec):
+    """Map builds against the committed fixture (no oracle run on this box)."""
+    kw = dict(rec["synth"])
+    if "rel_pose" in kw:
+        kw["rel_pose"] = tuple(kw["rel_pose"])
+    case = synth.map_case(**kw)
+    bkw = {_BUILDER_NAMES[k]: v for k, v in rec["builder"].items()}
+    shape, info = gpu_ctx.construct_map_from_scans(900, case["shape"], case["map_pose"], case["nodes"], **bkw)
+    want = rec["batch"]
+    assert (shape["rows"], shape["cols"]) == (want["rows"], want["cols"])
+    assert [shape["off_x"], shape["off_y"]] == [unhex(v) for v in want["off"]]
+    assert _fnv64(gpu_ctx.download_level(900, 0)) == want["hash"]
+    assert (info["rays"], info["cell_updates"], info["saturated_reads"]) == \
+        (want["rays"], want["updates"], want["saturated"])
+    shape = case["shape"]
+    gpu_ctx.upload_grid(901, np.zeros((shape["rows"], shape["cols"]), np.uint16))
+    for nd in case["nodes"]:
+        shape, _ = gpu_ctx.update_map_with_scan(901, shape, case["map_pose"], nd, **bkw)
+    want = rec["incremental"]
+    assert (shape["rows"], shape["cols"]) == (want["rows"], want["cols"])
+    assert [shape["off_x"], shape["off_y"]] == [unhex(v) for v in want["off"]]
+    assert _fnv64(gpu_ctx.download_level(901, 0)) == want["hash"]
+    gpu_ctx.release_grid(900)
+    gpu_ctx.release_grid(901)
