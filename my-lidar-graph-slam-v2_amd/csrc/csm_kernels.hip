@@ -53,6 +53,15 @@ __device__ __forceinline__ bool band_hit(int u, int w, int nk, int known_lo)
     return v <= -1 && v >= -(w - 1) && v + w - 1 >= known_lo;
 }
 
+/* acc + cell * mult as ONE v_mad_u32_u24. Left to itself the compiler pairs two
+ * gathers into v_mul, v_mul, v_add3 (1.5 VALU per gather instead of 1). */
+__device__ __forceinline__ uint32_t mad_u24(uint32_t cell, uint32_t mult, uint32_t acc)
+{
+    uint32_t out;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(out) : "v"(cell), "s"(mult), "v"(acc));
+    return out;
+}
+
 /* PositionToIndex on device, IEEE double, no contraction: bit-identical to
  * src/grid_map_new/grid_map_geometry.cpp:113-122 */
 __device__ __forceinline__ int cell_index(double pos, double off, double res)
@@ -500,7 +509,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                 const uint32_t m = STRIDED ? pbv >> 24 : pbv >> 16;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    acc[r] = __umul24(p[r * LSTRIDE], m) + acc[r];
+                    acc[r] = mad_u24(p[r * LSTRIDE], m, acc[r]);
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
