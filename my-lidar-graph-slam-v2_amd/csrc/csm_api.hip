@@ -76,6 +76,7 @@ struct csm_ctx {
     DevBuf m_rays, m_recs, m_cell, m_lists, m_cnt, m_lut;
     double m_lut_hit = -1.0, m_lut_miss = -1.0;   /* probabilities the update tables were built for */
     bool m_apply_attr = false;
+    hipEvent_t m_ev[2] = { nullptr, nullptr };    /* device_us of csm_map_build_info */
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -1009,6 +1010,9 @@ int csm_destroy(csm_ctx* ctx)
         }
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->m_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -423,12 +423,13 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
     unsigned long long counters[kMapCounters] = { 0 };
     counters[kMapKnownRow] = counters[kMapKnownCol] = ~0ull;
     const auto t1 = std::chrono::steady_clock::now();
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    if (info) {
-        HIP_TRY(ctx, hipEventCreate(&ev_a));
-        HIP_TRY(ctx, hipEventCreate(&ev_b));
-        HIP_TRY(ctx, hipEventRecord(ev_a, ctx->stream));
+    if (info && !ctx->m_ev[0]) {
+        HIP_TRY(ctx, hipEventCreate(&ctx->m_ev[0]));
+        HIP_TRY(ctx, hipEventCreate(&ctx->m_ev[1]));
     }
+    const hipEvent_t ev_a = ctx->m_ev[0], ev_b = ctx->m_ev[1];
+    if (info)
+        HIP_TRY(ctx, hipEventRecord(ev_a, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_nodes, table.data(), table.size() * sizeof(MapNode),
                                 hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mj.counters, counters, sizeof(counters), hipMemcpyHostToDevice, ctx->stream));
@@ -460,11 +461,8 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
     HIP_TRY(ctx, hipMemcpyAsync(counters, mj.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     float dev_ms = 0.f;
-    if (info) {
+    if (info)
         (void)hipEventElapsedTime(&dev_ms, ev_a, ev_b);
-        (void)hipEventDestroy(ev_a);
-        (void)hipEventDestroy(ev_b);
-    }
     if (counters[kMapError]) {
         free_levels(g, false);          /* the cells may be half updated: drop the map */
         ctx->grids.erase(map_id);
