@@ -154,6 +154,12 @@ int main(int argc, char** argv)
         const ScanMatchingSummary r = (prm[6] == 0.0 && prm[7] == 0.0)
                                           ? m->OptimizePose(q)
                                           : m->OptimizePose(q, prm[6], prm[7]);
+        int metricIds = 0;
+        ReportScanMatcherMetrics(m->Name(), r, s.mNumOfScans, [&](const std::string& id, double) {
+            metricIds += id.rfind("demo.", 0) == 0;
+        });
+        if (metricIds != 15)
+            return 4;
         std::printf("{\"found\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\", \"win\": [%d, %d, %d]}\n",
                     r.mPoseFound ? 1 : 0, r.mEstimatedPose.mX, r.mEstimatedPose.mY,
                     r.mEstimatedPose.mTheta, r.mScoreValue, r.mWinSizeX, r.mWinSizeY, r.mWinSizeTheta);

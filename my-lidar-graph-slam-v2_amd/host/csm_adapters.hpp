@@ -161,6 +161,35 @@ inline void FillSummary(const csm_summary& s, const RobotPose2D<double>& initial
 }
 } /* namespace detail */
 
+/* The 15 value sequences a matcher registers with the MetricManager and observes
+ * once per call (src/mapping/scan_matcher_correlative.cpp:37-70, 222-236), under
+ * the same ids: observe("<matcherName>.InputSetupTime", value), ... Ignored /
+ * processed nodes lose their meaning when every candidate is scored: reported
+ * as 0 and the number of candidates. The glue in the reference tree passes
+ * [&](const std::string& id, double v) { its ValueSequence for id ->Observe(v); }. */
+template <typename Observe>
+inline void ReportScanMatcherMetrics(const std::string& matcherName, const ScanMatchingSummary& s,
+                                     std::size_t numOfScans, Observe&& observe)
+{
+    const double dx = s.mEstimatedPose.mX - s.mMapLocalInitialPose.mX;
+    const double dy = s.mEstimatedPose.mY - s.mMapLocalInitialPose.mY;
+    observe(matcherName + ".InputSetupTime", s.mInputSetupTime);
+    observe(matcherName + ".OptimizationTime", s.mOptimizationTime);
+    observe(matcherName + ".DiffTranslation", std::sqrt(dx * dx + dy * dy));
+    observe(matcherName + ".DiffRotation", std::abs(s.mMapLocalInitialPose.mTheta - s.mEstimatedPose.mTheta));
+    observe(matcherName + ".WinSizeX", static_cast<double>(s.mWinSizeX));
+    observe(matcherName + ".WinSizeY", static_cast<double>(s.mWinSizeY));
+    observe(matcherName + ".WinSizeTheta", static_cast<double>(s.mWinSizeTheta));
+    observe(matcherName + ".StepSizeX", s.mStepSizeX);
+    observe(matcherName + ".StepSizeY", s.mStepSizeY);
+    observe(matcherName + ".StepSizeTheta", s.mStepSizeTheta);
+    observe(matcherName + ".NumOfIgnoredNodes", 0.0);
+    observe(matcherName + ".NumOfProcessedNodes", static_cast<double>(s.mNumOfCandidates));
+    observe(matcherName + ".ScoreValue", static_cast<double>(static_cast<float>(s.mScoreValue)));   /* a float sequence */
+    observe(matcherName + ".CostValue", s.mNormalizedCost);
+    observe(matcherName + ".NumOfScans", static_cast<double>(numOfScans));
+}
+
 class ScanMatcherCorrelativeHIP final {
 public:
     /* Constructor arguments as ScanMatcherCorrelative
