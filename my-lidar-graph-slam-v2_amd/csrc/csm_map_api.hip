@@ -89,11 +89,11 @@ int csm_host_map_resize(csm_map_shape* shape, const int32_t box[4], int32_t expa
     shape->rows = (int32_t)rows;
     shape->cols = (int32_t)cols;
     /* GridMapGeometry::Resize (src/grid_map_new/grid_map_geometry.cpp:61-72) */
-    shape->offset_x += shape->resolution * (b_min_x << lb);
-    shape->offset_y += shape->resolution * (b_min_y << lb);
+    shape->offset_x += shape->resolution * (b_min_x * block);      /* b_min may be negative: no shift */
+    shape->offset_y += shape->resolution * (b_min_y * block);
     if (shift_out) {
-        shift_out[0] = b_min_y << lb;
-        shift_out[1] = b_min_x << lb;
+        shift_out[0] = b_min_y * block;
+        shift_out[1] = b_min_x * block;
     }
     return CSM_OK;
 }
@@ -314,8 +314,6 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
         return fail(ctx, CSM_EINVAL, "resized map is out of range");
     const bool resized = !keep_cells || shift[0] != 0 || shift[1] != 0 || next.rows != shape->rows ||
                          next.cols != shape->cols;
-    const int lb = shape->log2_block_size;
-    const int b_min_y = shift[0] >> lb, b_min_x = shift[1] >> lb;     /* exact: multiples of the block */
     const int rows = next.rows, cols = next.cols;
     const double off_x = next.offset_x, off_y = next.offset_y;
     for (MapNode& t : table) {
@@ -360,7 +358,7 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
         base.win = 1;
         base.owned = true;
         base.cap = want;
-        const int shift_r = -(b_min_y << lb), shift_c = -(b_min_x << lb);
+        const int shift_r = -shift[0], shift_c = -shift[1];
         HIP_TRY(ctx, hipMemsetAsync(base.cells, 0, bytes, ctx->stream));
         HIP_TRY(ctx, hipMemcpy2DAsync(base.cells + (size_t)shift_r * pitch + shift_c, (size_t)pitch * 2,
                                       g.levels[0].cells, (size_t)g.pitch * 2, (size_t)g.cols * 2, g.rows,

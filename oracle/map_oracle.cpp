@@ -258,7 +258,8 @@ int orc_map_resize(OrcMapShape* shape, const double mapPose[3], const OrcScanNod
     const int bMinY = index_to_block(iMinY, shape->log2Block);
     const int bMaxX = index_to_block(iMaxX + blockSize - 1, shape->log2Block);
     const int bMaxY = index_to_block(iMaxY + blockSize - 1, shape->log2Block);
-    const int rowMin = bMinY << shape->log2Block, colMin = bMinX << shape->log2Block;
+    /* the reference shifts (bMin << log2Block); a multiplication avoids shifting a negative int */
+    const int rowMin = bMinY * blockSize, colMin = bMinX * blockSize;
     shape->rows = (bMaxY - bMinY) << shape->log2Block;
     shape->cols = (bMaxX - bMinX) << shape->log2Block;
     shape->offX += shape->res * colMin;            /* grid_map_geometry.cpp:61-72 */
@@ -331,8 +332,8 @@ int orc_map_expand(OrcMapShape* shape, const double mapPose[3], const OrcScanNod
     const int bMinX = index_to_block(ux0, shape->log2Block), bMinY = index_to_block(uy0, shape->log2Block);
     const int bMaxX = index_to_block(ux1 + blockSize - 1, shape->log2Block);
     const int bMaxY = index_to_block(uy1 + blockSize - 1, shape->log2Block);
-    *rowMin = bMinY << shape->log2Block;
-    *colMin = bMinX << shape->log2Block;
+    *rowMin = bMinY * blockSize;
+    *colMin = bMinX * blockSize;
     shape->rows = (bMaxY - bMinY) << shape->log2Block;
     shape->cols = (bMaxX - bMinX) << shape->log2Block;
     shape->offX += shape->res * *colMin;
