@@ -1364,7 +1364,8 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     int rc = level_for_window(ctx, *g, prm->low_resolution, &level);
     if (rc)
         return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    /* no wait here: a rebuilt coarse level is ordered before the search on the stream;
+     * input_setup_us is the host side of the set-up */
     const auto t1 = std::chrono::steady_clock::now();
 
     /* scan_matcher_correlative.cpp:130-146 */
