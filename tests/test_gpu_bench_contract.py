@@ -43,3 +43,20 @@ def test_extra_workloads(workload):
     for k in REQUIRED:
         assert k in d, k
     assert d["value"] > 0 and "workload" in d["config"]
+
+
+def test_two_rank_rehearsal():
+    """The N > 1 control flow of bench.py (rendezvous, barrier, max-over-ranks
+    timing, all-gather of the records, rank-0 line) with two ranks sharing this
+    box's one GPU over gloo (CSM_BENCH_REHEARSE=1); the numbers mean nothing."""
+    env = dict(os.environ, CSM_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "cpu_baseline" not in d
