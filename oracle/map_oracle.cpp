@@ -144,11 +144,11 @@ void ray_cells(int sx, int sy, int ex, int ey, int scale, std::vector<Cell>& out
     int64_t sub = (2 * (sy % scale) + 1) * dx;         /* :125 */
     if (up < 0)
         sub = denom - sub;
-    const int firstPixel = 2 * scale - (2 * (sx % scale) + 1);   /* :131-133 */
-    const int lastPixel = 2 * (ex % scale) + 1;
+    const int headSpan = 2 * scale - (2 * (sx % scale) + 1);   /* :131-133 */
+    const int tailSpan = 2 * (ex % scale) + 1;
     int x = startX, y = startY;
     visit(x, y);
-    sub += rise * firstPixel;                          /* :139 */
+    sub += rise * headSpan;                          /* :139 */
     for (;;) {                                         /* :144-166 / :192-217 */
         visit(x, y);
         while (sub > denom) {
@@ -165,7 +165,7 @@ void ray_cells(int sx, int sy, int ex, int ey, int scale, std::vector<Cell>& out
             break;
         sub += 2 * rise * scale;
     }
-    sub += rise * lastPixel;                           /* :169-179 / :220-230 */
+    sub += rise * tailSpan;                           /* :169-179 / :220-230 */
     visit(x, y);
     while (sub > denom) {
         sub -= denom;
