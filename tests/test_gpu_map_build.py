@@ -261,3 +261,33 @@ def test_map_many_scans_fine_resolution(gpu_ctx, oracle):
     shape, grid, info = _check(gpu_ctx, oracle, case, 470)
     assert info["rays"] > 60000 and info["cell_updates"] > 4e6
     gpu_ctx.release_grid(470)
+
+
+def test_frontend_loop_over_a_trajectory(gpu_ctx, oracle):
+    """25 scans in a row, as the frontend runs them: rebuild the latest map from
+    the last 10 scan nodes in the frame the previous build left, match the new
+    scan against it, move on. Every step is compared with the CPU pipeline."""
+    case = synth.map_case(77, n_scans=26, n_beams=360, step=0.15)
+    nodes = case["nodes"]
+    shape_dev = shape_cpu = case["shape"]
+    for k in range(1, 26):
+        window = nodes[max(0, k - 10):k]
+        map_pose = window[0]["pose"]
+        shape_cpu, grid, stats = oracle.construct_map(shape_cpu, map_pose, window)
+        shape_dev, info = gpu_ctx.construct_map_from_scans(600, shape_dev, map_pose, window)
+        assert shape_dev == shape_cpu, k
+        assert np.array_equal(gpu_ctx.download_level(600, 0), grid), k
+        assert info["cell_updates"] == stats["updates"]
+        new = nodes[k]
+        c, s_ = math.cos(map_pose[2]), math.sin(map_pose[2])
+        dx, dy = new["pose"][0] + 0.04 - map_pose[0], new["pose"][1] - 0.03 - map_pose[1]
+        init = (c * dx + s_ * dy, -s_ * dx + c * dy, new["pose"][2] + 0.01 - map_pose[2])
+        geom = (shape_cpu["res"], shape_cpu["off_x"], shape_cpu["off_y"])
+        out = gpu_ctx.correlative_match(600, geom, new["angles"], new["ranges"], new["rel_pose"], init,
+                                        0.5, 0.5, 0.2, 4, 0.0, 0.0)
+        want = oracle.csm(dict(grid=grid, geom=geom, angles=new["angles"], ranges=new["ranges"],
+                               rel_pose=new["rel_pose"], init_pose=init), 0.5, 0.5, 0.2, 4)
+        assert out["pose_found"] == want["found"], k
+        assert list(out["estimated_pose"]) == want["estimatedPose"], k
+        assert out["raw"]["score"] == want["scoreMax"], k
+    gpu_ctx.release_grid(600)
