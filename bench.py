@@ -4,8 +4,10 @@
 Workload at every N: BASELINE.json configs[1] per GPU -- frontend CSM, 1080-beam
 scan over 270 deg, 400x400 grid @ 5 cm, +-2 m / +-30 deg window at 5 cm / 0.5 deg,
 L = 4 (121 x 84 x 84 = 853,776 candidate poses per scan, 2160 algorithmic bytes
-each). One step = SCANS_PER_STEP independent scans scored back to back with hit
-indices and grid already resident in HBM. With N > 1 every rank scores its own
+each). One step = SCANS_PER_STEP (32) independent scans, hit indices and grid
+already resident in HBM, scored by one batched launch chain
+(csm_score_windows_dev; CSM_BENCH_MODE=streams scores them one launch chain per
+scan instead). With N > 1 every rank scores its own
 scans (weak scaling, no data-path collective) and the per-scan best records
 (48 B) are all-gathered over RCCL at the end of each step, as the loop
 detector's result exchange does.
@@ -26,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "my-lidar-graph-slam-v2_amd"))
 
-SCANS_PER_STEP = 16     # a step's scans are independent; 16 keep the per-step all-gather below 3 % at N = 8
+SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "32"))   # independent scans per step
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -115,11 +117,13 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse):
         queries.append(dict(map_id=i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
                             rel_pose=(0.0, 0.0, 0.0), init_pose=init))
     params = (2.5, 2.5, 0.5, 2, 0.55, 0.6)
+    # the query array is marshalled once, as a C++ caller holds it (csm_loop_query[])
+    prepared = ctx.prepare_queries(queries)
 
     def step():
-        outs = ctx.bnb_match_batch(queries, *params)
+        outs = ctx.bnb_match_batch(prepared, *params, as_records=True)
         if world > 1:
-            rec = torch.from_numpy(parallel.records_to_bytes([o["raw"] for o in outs]).reshape(-1))
+            rec = torch.from_numpy(outs.record_bytes())
             if not rehearse:
                 rec = rec.to(dev)
             out = torch.zeros(world * rec.numel(), dtype=torch.uint8, device=rec.device)
@@ -149,7 +153,8 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
-        leaves = sum(o["candidates"] for o in outs)
+        leaves = outs.total("candidates")
+        outs = list(outs)
         alg = 2.0 * 1080 * leaves
         avg = fine_ms / max(1, fine_n) * 1e-3
         print(json.dumps({
@@ -160,7 +165,7 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse):
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "configs[2] per GPU: branch-and-bound loop detection, 1 scan vs 256 "
                                    "submaps, 3-level grids, 2.5 m x 2.5 m x 0.5 rad, thresholds 0.55/0.6; "
-                                   "host-inclusive batch call (scans in host memory, maps resident)",
+                                   "host-inclusive batch call (scans in host memory, query array marshalled once, maps resident)",
                        "leaves_per_step_per_gpu": leaves, "found": sum(o["pose_found"] for o in outs),
                        "flagged": sum(1 for o in outs if o["raw"]["flags"]),
                        "parallelism": "queries sharded per GPU, all-gather of 48-B records"
@@ -284,6 +289,9 @@ def main():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra host-inclusive batched measurement (for profiling runs: its "
+                         "launches share the dominant kernel's symbol)")
     ap.add_argument("--workload", choices=["csm", "loop", "map"], default="csm",
                     help="csm (default): BASELINE configs[1]; loop: configs[2]/[3], 256 candidate "
                          "submaps per GPU through the branch-and-bound batch + all-gather; map: the "
@@ -329,7 +337,11 @@ def main():
     # matcher contexts (one HIP stream each), so one scan's small kernels (bin,
     # arg-max, finalize: a few workgroups each) run beside another scan's
     # full-chip scoring kernel instead of leaving the chip idle.
-    n_streams = max(1, min(SCANS_PER_STEP, int(os.environ.get("CSM_BENCH_STREAMS", "2"))))
+    # CSM_BENCH_MODE=batch (default): the step's scans go through the batched launch
+    # chain in one call (csm_score_windows_dev); =streams: one launch chain per scan
+    # (csm_score_window_dev), alternating between N_STREAMS contexts.
+    batch_mode = os.environ.get("CSM_BENCH_MODE", "batch") == "batch"
+    n_streams = 1 if batch_mode else max(1, min(SCANS_PER_STEP, int(os.environ.get("CSM_BENCH_STREAMS", "2"))))
     stream = torch.cuda.current_stream(dev)
     side_streams = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
     ctxs = []
@@ -357,14 +369,20 @@ def main():
     results = torch.zeros(SCANS_PER_STEP * rec_bytes, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * SCANS_PER_STEP * rec_bytes, dtype=torch.uint8, device=dev)
 
+    prepared = ctx.prepare_windows([1] * SCANS_PER_STEP, windows, [c.data_ptr() for c in cols],
+                                   [r.data_ptr() for r in rows_])
+
     def step():
-        for s2 in side_streams:
-            s2.wait_stream(stream)           # the previous step's all-gather has read `results`
-        for i in range(SCANS_PER_STEP):
-            ctxs[i % n_streams].score_window_dev(1, windows[i], cols[i].data_ptr(), rows_[i].data_ptr(),
-                                                 results.data_ptr() + i * rec_bytes)
-        for s2 in side_streams:
-            stream.wait_stream(s2)
+        if batch_mode:
+            ctx.score_windows_dev(prepared, results.data_ptr())
+        else:
+            for s2 in side_streams:
+                s2.wait_stream(stream)       # the previous step's all-gather has read `results`
+            for i in range(SCANS_PER_STEP):
+                ctxs[i % n_streams].score_window_dev(1, windows[i], cols[i].data_ptr(), rows_[i].data_ptr(),
+                                                     results.data_ptr() + i * rec_bytes)
+            for s2 in side_streams:
+                stream.wait_stream(s2)
         if world > 1:
             if rehearse:
                 host = results.cpu()
@@ -419,7 +437,7 @@ def main():
     # the device, 64 queries per call) -- what LoopDetectorCorrelative-style
     # callers get when queries are independent
     batched = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         qs = []
         for rep in range(max(1, 64 // SCANS_PER_STEP)):
             for sc in wl["scans"]:
@@ -428,11 +446,12 @@ def main():
                                rel_pose=sc["rel_pose"], init_pose=init))
         ctx_b = api.Context(dev_index)       # its own stream, as a detector object has
         ctx_b.upload_grid(1, wl["grid"])
-        ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0)
+        qs = ctx_b.prepare_queries(qs)       # the csm_loop_query[] a C++ caller holds
+        ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0, as_records=True)
         samples = []
         for _ in range(9):
             tb0 = time.perf_counter()
-            outs = ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0)
+            outs = ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0, as_records=True)
             samples.append(time.perf_counter() - tb0)
         tb = sorted(samples)[len(samples) // 2]      # median: host calls jitter
         ctx_b.enable_kernel_timing(True)
@@ -440,8 +459,8 @@ def main():
         ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0)
         kms = {k: ctx_b.kernel_time(k)[0] for k in ("project", "bin", "score_coarse", "score_fine", "finalize")}
         ctx_b.close()
-        batched = {"value": sum(o["candidates"] for o in outs) / tb, "unit": "candidate poses/s",
-                   "queries_per_call": len(qs), "ms_per_call": tb * 1e3, "kernel_ms": kms,
+        batched = {"value": outs.total("candidates") / tb, "unit": "candidate poses/s",
+                   "queries_per_call": qs.n, "ms_per_call": tb * 1e3, "kernel_ms": kms,
                    "note": "median of 9 calls; host-inclusive: scans in host memory, projection + "
                            "search on device, summaries back on the host; one GPU"}
 
@@ -457,7 +476,8 @@ def main():
     if rank == 0:
         total = cands_per_step * args.steps * world
         value = total / dt
-        cands_per_launch = cands_per_step / SCANS_PER_STEP
+        windows_per_launch = SCANS_PER_STEP if batch_mode else 1
+        cands_per_launch = cands_per_step / SCANS_PER_STEP * windows_per_launch
         alg_bytes = 2.0 * n_beams * cands_per_launch
         avg_fine_s = (fine_ms / max(1, fine_n)) * 1e-3
         achieved = alg_bytes / avg_fine_s / 1e9 if avg_fine_s > 0 else 0.0
@@ -478,8 +498,10 @@ def main():
                 "workload": "configs[1]: frontend CSM, 1080-beam scan, 400x400@5cm grid, "
                             "+-2 m/+-30 deg window at 5 cm/0.5 deg, L=4",
                 "scans_per_step": SCANS_PER_STEP,
+                "mode": "batch: csm_score_windows_dev, one launch chain per step" if batch_mode
+                        else "streams: csm_score_window_dev per scan on %d stream(s)" % n_streams,
                 "streams": n_streams,
-                "candidates_per_scan": cands_per_launch,
+                "candidates_per_scan": cands_per_step / SCANS_PER_STEP,
                 "beams": n_beams,
                 "parallelism": "scans sharded per GPU, all-gather of 48-B best records" if world > 1
                                else "single GPU",
@@ -487,7 +509,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_score (fine level)",
+                "kernel": "k_score_batch (fine level, %d windows per launch)" % SCANS_PER_STEP if batch_mode
+                          else "k_score (fine level)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -223,6 +223,16 @@ int  csm_score_window(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
 int  csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
                           const int32_t* hit_col_dev, const int32_t* hit_row_dev,
                           csm_result* out_dev);
+/* csm_score_window_dev for n independent windows in one launch chain (the
+ * batched kernels of the loop detectors): windows[i] on map_ids[i] with the
+ * device-resident hit indices hit_col_dev[i] / hit_row_dev[i], result i in
+ * out_dev[i] (device). Asynchronous; a record that carries a key-tie or
+ * edge-band flag is finished by scoring that window again with
+ * csm_score_window_dev() + csm_resolve_window_dev(). Coarse levels as for the
+ * single call (csm_build_pyramid; windows[i].coarse_level). */
+int  csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids,
+                           const csm_window* windows, const int32_t* const* hit_col_dev,
+                           const int32_t* const* hit_row_dev, csm_result* out_dev);
 /* Synchronises, reads *out_dev and, when it carries a key tie or an edge-band
  * flag, runs the exact device paths (f64 tie replay / literal sequential
  * sweep) for the window just scored with csm_score_window_dev(); no-op

@@ -144,6 +144,8 @@ SIGNATURES = {
                                    C.c_void_p, _P(Result)]),
     "csm_score_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "csm_score_windows_dev": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "csm_resolve_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "csm_score_window_dump": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,

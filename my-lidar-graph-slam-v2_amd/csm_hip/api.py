@@ -45,6 +45,39 @@ def summary_to_dict(s):
                 candidates=int(s.candidates), raw=result_to_dict(s.raw))
 
 
+class PreparedQueries:
+    """Context.prepare_queries()'s result: the csm_loop_query array plus the
+    numpy arrays its pointers refer to."""
+
+    def __init__(self, arr, keep):
+        self.arr, self.keep, self.n = arr, keep, len(arr)
+
+
+class SummaryArray:
+    """The csm_summary array of a batch call, converted on demand."""
+
+    def __init__(self, out):
+        self.out = out
+
+    def __len__(self):
+        return len(self.out)
+
+    def __getitem__(self, i):
+        return summary_to_dict(self.out[i])
+
+    def __iter__(self):
+        return (summary_to_dict(o) for o in self.out)
+
+    def record_bytes(self):
+        """The 48-byte csm_result of every query, back to back (what the ranks all-gather)."""
+        n, size, off = len(self.out), C.sizeof(L.Summary), L.Summary.raw.offset
+        flat = np.frombuffer(self.out, dtype=np.uint8).reshape(n, size)
+        return np.ascontiguousarray(flat[:, off:off + C.sizeof(L.Result)]).reshape(-1)
+
+    def total(self, field):
+        return sum(int(getattr(o, field)) for o in self.out)
+
+
 # ---- host-only helpers (no GPU needed) ----
 
 def host_search_step(resolution, ranges):
@@ -214,6 +247,23 @@ class Context:
                                                   C.c_void_p(col_ptr), C.c_void_p(row_ptr),
                                                   C.c_void_p(out_ptr)))
 
+    def prepare_windows(self, map_ids, windows, col_ptrs, row_ptrs):
+        """The argument arrays of score_windows_dev(), built once for a batch
+        that is scored repeatedly."""
+        n = len(windows)
+        ids = (C.c_uint64 * n)(*map_ids)
+        wins = (L.Window * n)(*windows)
+        cols = (C.c_void_p * n)(*col_ptrs)
+        rows = (C.c_void_p * n)(*row_ptrs)
+        return n, ids, wins, cols, rows
+
+    def score_windows_dev(self, prepared, out_ptr):
+        """csm_score_window_dev for many windows in one launch chain; `prepared`
+        from prepare_windows(); out_ptr: device pointer to n 48-byte records."""
+        n, ids, wins, cols, rows = prepared
+        self._check(self.lib.csm_score_windows_dev(self._ctx, n, ids, wins, cols, rows,
+                                                   C.c_void_p(out_ptr)))
+
     def correlative_match(self, map_id, geom, angles, ranges, rel_pose, init_pose,
                           range_x, range_y, range_theta, low_resolution,
                           score_threshold=0.0, known_rate_threshold=0.0):
@@ -304,7 +354,13 @@ class Context:
                                                    _ptr(init), C.byref(p), C.byref(out)))
         return summary_to_dict(out)
 
-    def _flatten_queries(self, queries):
+    def prepare_queries(self, queries):
+        """Flatten a list of dict(map_id, geom, angles, ranges, rel_pose,
+        init_pose) into the C array the batch entry points take. A caller that
+        repeats a batch (or a C++ caller, which holds such an array anyway)
+        passes the result instead of the list and skips the per-call marshalling."""
+        if isinstance(queries, PreparedQueries):
+            return queries
         n = len(queries)
         arr = (L.LoopQuery * n)()
         keep = []
@@ -318,44 +374,33 @@ class Context:
             arr[i].scan.n_points = a.size
             arr[i].scan.relative_sensor_pose[:] = list(q["rel_pose"])
             arr[i].initial_pose[:] = list(q["init_pose"])
-        return arr, keep
+        return PreparedQueries(arr, keep)
 
     def correlative_match_batch(self, queries, range_x, range_y, range_theta, low_resolution,
-                                score_threshold, known_rate_threshold):
-        """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose)."""
-        n = len(queries)
-        arr, keep = self._flatten_queries(queries)
+                                score_threshold, known_rate_threshold, as_records=False):
+        """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose)
+        or prepare_queries()'s result. as_records: return the C summaries
+        (SummaryArray) instead of dicts."""
+        prep = self.prepare_queries(queries)
         p = L.CorrelativeParams()
         p.range_x, p.range_y, p.range_theta = range_x, range_y, range_theta
         p.low_resolution = low_resolution
         p.score_threshold, p.known_rate_threshold = score_threshold, known_rate_threshold
-        out = (L.Summary * n)()
-        self._check(self.lib.csm_correlative_match_batch(self._ctx, arr, n, C.byref(p), out))
-        return [summary_to_dict(o) for o in out]
+        out = (L.Summary * prep.n)()
+        self._check(self.lib.csm_correlative_match_batch(self._ctx, prep.arr, prep.n, C.byref(p), out))
+        return SummaryArray(out) if as_records else [summary_to_dict(o) for o in out]
 
     def bnb_match_batch(self, queries, range_x, range_y, range_theta, node_height_max,
-                        score_threshold, known_rate_threshold):
-        """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose)."""
-        n = len(queries)
-        arr = (L.LoopQuery * n)()
-        keep = []
-        for i, q in enumerate(queries):
-            a, r = _f64(q["angles"]), _f64(q["ranges"])
-            keep.append((a, r))
-            arr[i].map_id = q["map_id"]
-            arr[i].geometry = L.Geometry(*q["geom"])
-            arr[i].scan.angles = a.ctypes.data_as(C.POINTER(C.c_double))
-            arr[i].scan.ranges = r.ctypes.data_as(C.POINTER(C.c_double))
-            arr[i].scan.n_points = a.size
-            arr[i].scan.relative_sensor_pose[:] = list(q["rel_pose"])
-            arr[i].initial_pose[:] = list(q["init_pose"])
+                        score_threshold, known_rate_threshold, as_records=False):
+        """As correlative_match_batch, for the branch-and-bound detector."""
+        prep = self.prepare_queries(queries)
         p = L.BnbParams()
         p.range_x, p.range_y, p.range_theta = range_x, range_y, range_theta
         p.node_height_max = node_height_max
         p.score_threshold, p.known_rate_threshold = score_threshold, known_rate_threshold
-        out = (L.Summary * n)()
-        self._check(self.lib.csm_bnb_match_batch(self._ctx, arr, n, C.byref(p), out))
-        return [summary_to_dict(o) for o in out]
+        out = (L.Summary * prep.n)()
+        self._check(self.lib.csm_bnb_match_batch(self._ctx, prep.arr, prep.n, C.byref(p), out))
+        return SummaryArray(out) if as_records else [summary_to_dict(o) for o in out]
 
     def enable_kernel_timing(self, on=True):
         self._check(self.lib.csm_enable_kernel_timing(self._ctx, 1 if on else 0))

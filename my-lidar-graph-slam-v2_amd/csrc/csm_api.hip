@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <limits>
 #include <cmath>
@@ -1651,14 +1652,28 @@ struct BatchSpec {
     const csm_correlative_params* csm_params = nullptr;
 };
 
+/* csm_score_windows_dev: the windows and hit indices are given (device
+ * resident, already projected), the results stay on the device, nothing waits. */
+struct ResidentBatch {
+    const csm_window* windows;            /* [n] */
+    const int32_t* const* hit_col;        /* [n] device pointers, [n_theta][n_points] each */
+    const int32_t* const* hit_row;
+    csm_result* out_dev;                  /* [n] device */
+};
+
 /* One group of queries that share (nx, ny): the whole device pipeline. */
 int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vector<int>& idx,
                     const std::vector<std::vector<int>>& levels, const BatchSpec& spec,
-                    csm_summary* out)
+                    csm_summary* out, const ResidentBatch* resident = nullptr)
 {
     const int H = spec.H;
     const int nq = (int)idx.size();
     std::vector<BatchPrep> pp(nq);
+    std::vector<csm_summary> scratch_out;
+    if (resident) {                       /* no host summaries in this mode */
+        scratch_out.assign((size_t)*std::max_element(idx.begin(), idx.end()) + 1, csm_summary {});
+        out = scratch_out.data();
+    }
     int rc;
 
     /* ---- host set-up: window, projection products (threaded over queries) ---- */
@@ -1672,14 +1687,23 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         p.grid = find_grid(ctx, q.map_id);
         for (int h = 0; h <= H; ++h)
             p.level[h] = levels[idx[k]][h];
-        csm_host_compound(q.initial_pose, q.scan.relative_sensor_pose, o.sensor_pose);
-        csm_host_search_step(q.geometry.resolution, q.scan.ranges, q.scan.n_points, &o.step_x,
-                             &o.step_y, &o.step_theta);
-        o.win_x = p.win_x = csm_host_window(spec.range_x, o.step_x);
-        o.win_y = p.win_y = csm_host_window(spec.range_y, o.step_y);
-        o.win_theta = p.win_t = csm_host_window(spec.range_theta, o.step_theta);
-        p.n_theta = 2 * p.win_t + 1;
-        p.n = q.scan.n_points;
+        if (resident) {
+            const csm_window& w = resident->windows[idx[k]];
+            p.win_x = w.win_x;
+            p.win_y = w.win_y;
+            p.win_t = (w.n_theta - 1) / 2;
+            p.n_theta = w.n_theta;
+            p.n = w.n_points;
+        } else {
+            csm_host_compound(q.initial_pose, q.scan.relative_sensor_pose, o.sensor_pose);
+            csm_host_search_step(q.geometry.resolution, q.scan.ranges, q.scan.n_points, &o.step_x,
+                                 &o.step_y, &o.step_theta);
+            o.win_x = p.win_x = csm_host_window(spec.range_x, o.step_x);
+            o.win_y = p.win_y = csm_host_window(spec.range_y, o.step_y);
+            o.win_theta = p.win_t = csm_host_window(spec.range_theta, o.step_theta);
+            p.n_theta = 2 * p.win_t + 1;
+            p.n = q.scan.n_points;
+        }
         const int big = spec.unit;
         p.nx = ceil_div(2 * p.win_x + 1, big) * big;
         p.ny = ceil_div(2 * p.win_y + 1, big) * big;
@@ -1710,8 +1734,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         scan_off[k] = scan_total;
         scan_total += 2 * (size_t)pp[k].n;
     }
-    std::vector<double> scans(scan_total);
-    for (int k = 0; k < nq; ++k) {
+    std::vector<double> scans(resident ? 0 : scan_total);
+    for (int k = 0; k < nq && !resident; ++k) {
         const csm_loop_query& q = queries[idx[k]];
         std::memcpy(scans.data() + scan_off[k], q.scan.angles, (size_t)pp[k].n * 8);
         std::memcpy(scans.data() + scan_off[k] + pp[k].n, q.scan.ranges, (size_t)pp[k].n * 8);
@@ -1723,7 +1747,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         if (!plan_pass(nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
             return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
                         spec.stride[h]);
-    {
+    if (resident) {
+        lp[0].weighted = resident->windows[idx[0]].merge_mode == 0;
+    } else {
         const csm_loop_query& q0 = queries[idx[0]];
         lp[0].weighted = merging_pays(q0.scan.angles, q0.scan.ranges, q0.scan.n_points,
                                       q0.geometry.resolution);
@@ -1742,8 +1768,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         p.best_off = best_total;
         best_total += (size_t)p.n_theta * ncb;
     }
-    if ((rc = ensure(ctx, ctx->b_prod, scan_total * 8 + 64))) return rc;
-    if ((rc = ensure(ctx, ctx->b_hits, hit_total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->b_prod, (resident ? 0 : scan_total * 8) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_hits, (resident ? 0 : hit_total * 8) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_sorted, hit_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_sorted_rc, hit_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tile_total * sizeof(TileRec)))) return rc;
@@ -1768,7 +1794,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     csm_result* d_out = reinterpret_cast<csm_result*>(ctx->b_out.p);
     uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_out + nq);
 
-    HIP_TRY(ctx, hipMemcpyAsync(d_scans, scans.data(), scan_total * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!resident)
+        HIP_TRY(ctx, hipMemcpyAsync(d_scans, scans.data(), scan_total * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, (size_t)nq * 4, ctx->stream));
     if (lvl_total)
         HIP_TRY(ctx, hipMemsetAsync(d_lvl_s, 0, lvl_total * 8, ctx->stream));
@@ -1784,14 +1811,15 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         const BatchPrep& p = pp[k];
         const DeviceGrid& g = *p.grid;
         const int x_lo = -p.win_x, y_lo = -p.win_y;
-        const int min_known = csm_host_min_known(p.n, spec.known_thr);
+        const int min_known = resident ? resident->windows[idx[k]].min_known
+                                       : csm_host_min_known(p.n, spec.known_thr);
 
         ProjJob& I = ij[k];
         std::memset(&I, 0, sizeof(I));
         I.angles = d_scans + scan_off[k];
         I.ranges = d_scans + scan_off[k] + p.n;
-        I.hit_col = d_col + p.hit_off;
-        I.hit_row = d_row + p.hit_off;
+        I.hit_col = resident ? const_cast<int32_t*>(resident->hit_col[idx[k]]) : d_col + p.hit_off;
+        I.hit_row = resident ? const_cast<int32_t*>(resident->hit_row[idx[k]]) : d_row + p.hit_off;
         I.flags = d_flags + k;
         I.n_theta = p.n_theta;
         I.n_points = p.n;
@@ -1917,10 +1945,10 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         Z.hit_col = I.hit_col;
         Z.hit_row = I.hit_row;
         Z.n_points = p.n;
-        Z.score_thr = spec.score_thr;
+        Z.score_thr = resident ? resident->windows[idx[k]].score_threshold : spec.score_thr;
         Z.lut = ctx->lut_dev;
         Z.flags_in = d_flags + k;
-        Z.out = d_out + k;
+        Z.out = resident ? resident->out_dev + idx[k] : d_out + k;
     }
     /* upload the job tables (one buffer, 16-byte aligned sections) */
     char* jb = reinterpret_cast<char*>(ctx->b_jobs.p);
@@ -1941,7 +1969,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         HIP_TRY(ctx, put(sj[h].data(), nq * sizeof(ScoreJob), &d_sj[h]));
 
     /* ---- launches ---- */
-    {
+    if (!resident) {
         ScopedTimer tm(ctx, "project");
         hipLaunchKernelGGL(k_project_batch, dim3(ceil_div(n_points_max, kBlock), n_theta_max, nq),
                            dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ProjJob*>(d_ij));
@@ -1979,6 +2007,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
                            reinterpret_cast<const FinalJob*>(d_fj));
         HIP_TRY(ctx, hipGetLastError());
     }
+    if (resident)
+        return CSM_OK;                      /* asynchronous: the records stay on the device */
     std::vector<csm_result> res(nq);
     HIP_TRY(ctx, hipMemcpyAsync(res.data(), d_out, (size_t)nq * sizeof(csm_result),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -2268,6 +2298,57 @@ int csm_grid_search_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     csm_host_move_backward(out->best_sensor_pose, scan->relative_sensor_pose, out->estimated_pose);
     out->optimization_us =
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return CSM_OK;
+}
+
+/* csm_score_window_dev for many windows at once: one launch chain (k_bin_batch,
+ * the batched scoring kernels, k_finalize_batch) over all of them. */
+int csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, const csm_window* windows,
+                          const int32_t* const* hit_col_dev, const int32_t* const* hit_row_dev,
+                          csm_result* out_dev)
+{
+    if (!ctx || n < 1 || !map_ids || !windows || !hit_col_dev || !hit_row_dev || !out_dev)
+        return fail(ctx, CSM_EINVAL, "csm_score_windows_dev: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<csm_loop_query> queries((size_t)n);
+    std::vector<std::vector<int>> levels((size_t)n, std::vector<int>(2, 0));
+    /* windows that share the candidate domain, the coarse window and the merge mode go together */
+    std::map<std::array<int, 4>, std::vector<int>> groups;
+    for (int i = 0; i < n; ++i) {
+        const csm_window& w = windows[i];
+        if (w.n_theta < 1 || (w.n_theta & 1) == 0 || w.n_points < 1 || w.win_x < 0 || w.win_y < 0 ||
+            w.low_resolution < 1 || !hit_col_dev[i] || !hit_row_dev[i])
+            return fail(ctx, CSM_EINVAL, "window %d: bad window", i);
+        DeviceGrid* g = find_grid(ctx, map_ids[i]);
+        if (!g)
+            return fail(ctx, CSM_ENOENT, "window %d: map %llu not resident", i,
+                        (unsigned long long)map_ids[i]);
+        const int L = w.low_resolution;
+        if (L > 1) {
+            if (w.coarse_level < 0 || w.coarse_level >= (int)g->levels.size() ||
+                g->levels[w.coarse_level].stale || g->levels[w.coarse_level].win != L)
+                return fail(ctx, CSM_ENOENT, "window %d: level %d does not hold box-max(%d)", i,
+                            w.coarse_level, L);
+            levels[i][1] = w.coarse_level;
+        }
+        std::memset(&queries[i], 0, sizeof(csm_loop_query));
+        queries[i].map_id = map_ids[i];
+        const int nx = ceil_div(2 * w.win_x + 1, L) * L, ny = ceil_div(2 * w.win_y + 1, L) * L;
+        groups[{ nx, ny, L, w.merge_mode }].push_back(i);
+    }
+    ResidentBatch resident { windows, hit_col_dev, hit_row_dev, out_dev };
+    for (auto& kv : groups) {
+        const int L = kv.first[2];
+        BatchSpec spec;
+        spec.bnb = false;
+        spec.H = L > 1 ? 1 : 0;
+        spec.stride[0] = 1;
+        spec.stride[1] = L;
+        spec.unit = L;
+        int rc = run_batch_group(ctx, queries.data(), kv.second, levels, spec, nullptr, &resident);
+        if (rc)
+            return rc;
+    }
     return CSM_OK;
 }
 

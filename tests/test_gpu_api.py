@@ -87,3 +87,59 @@ def test_pyramid_is_cached_per_map_id(gpu_ctx, oracle):
     for lvl, win in enumerate([1, 2, 4, 8]):
         assert np.array_equal(gpu_ctx.download_level(77, lvl), oracle.boxmax(case["grid"], win))
     gpu_ctx.release_grid(77)
+
+
+def test_batched_device_resident_windows(gpu_ctx, oracle):
+    """csm_score_windows_dev: many device-resident windows in one launch chain
+    give the records csm_score_window_dev gives one by one (different maps,
+    window sizes, coarse windows, thresholds and merge modes in one call)."""
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    specs = [(0, 1.0, 1.0, 10, 4, 0, 0.0), (1, 1.0, 1.0, 10, 4, 0, 0.0), (2, 0.6, 0.8, 6, 5, 0, 0.2),
+             (3, 1.0, 1.0, 10, 4, 1, 0.0), (4, 0.5, 0.5, 8, 1, 0, 0.0), (5, 1.0, 1.0, 10, 4, 0, 0.3)]
+    ids, windows, cols, rows, keep, lits = [], [], [], [], [], []
+    for k, (seed, rx, ry, rt_deg, Lr, merge, thr) in enumerate(specs):
+        case = synth.csm_case(seed, n_beams=360 + 60 * (k % 3))
+        rt = math.radians(rt_deg)
+        sx, sy, st = api.host_search_step(case["geom"][0], case["ranges"])
+        wx, wy, wt = api.host_window(rx, sx), api.host_window(ry, sy), api.host_window(rt, st)
+        col, row = api.host_project(case["geom"], case["init_pose"], st, wt, case["angles"], case["ranges"])
+        ctx.upload_grid(700 + k, case["grid"])
+        ctx.build_pyramid(700 + k, [1, Lr] if Lr > 1 else [1])
+        n = len(case["angles"])
+        w = ctx.make_window(2 * wt + 1, n, wx, wy, Lr, 1 if Lr > 1 else 0, api.host_min_known(n, 0.0), thr,
+                            merge_mode=merge)
+        c_d, r_d = torch.from_numpy(col).to(dev), torch.from_numpy(row).to(dev)
+        keep += [c_d, r_d]
+        ids.append(700 + k)
+        windows.append(w)
+        cols.append(c_d.data_ptr())
+        rows.append(r_d.data_ptr())
+        lits.append(oracle.csm(case, rx, ry, rt, Lr, thr, 0.0))
+    n = len(specs)
+    single = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+    for k in range(n):
+        ctx.score_window_dev(ids[k], windows[k], cols[k], rows[k], single.data_ptr() + 48 * k)
+    batch = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+    prepared = ctx.prepare_windows(ids, windows, cols, rows)
+    ctx.score_windows_dev(prepared, batch.data_ptr())
+    ctx.score_windows_dev(prepared, batch.data_ptr())          # repeatable
+    torch.cuda.synchronize(dev)
+    a = single.cpu().numpy().reshape(n, 48)
+    b = batch.cpu().numpy().reshape(n, 48)
+    for k in range(n):
+        ra, rb = L.Result.from_buffer_copy(a[k].tobytes()), L.Result.from_buffer_copy(b[k].tobytes())
+        for f in ("found", "best_x", "best_y", "best_theta", "key", "sum_values", "known", "score"):
+            assert getattr(ra, f) == getattr(rb, f), (k, f)
+        assert (ra.flags & 3) == (rb.flags & 3)
+        if not (rb.flags & 3):                                   # not flagged: final as it stands
+            lit = lits[k]
+            assert rb.found == lit["found"]
+            if lit["found"]:
+                assert (rb.best_x, rb.best_y, rb.best_theta) == (lit["bestX"], lit["bestY"], lit["bestT"])
+                assert rb.score == lit["scoreMax"]
+    with pytest.raises(api.CsmError):
+        bad = ctx.prepare_windows([999999], windows[:1], cols[:1], rows[:1])
+        ctx.score_windows_dev(bad, batch.data_ptr())
+    ctx.close()
