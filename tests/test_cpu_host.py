@@ -115,3 +115,25 @@ def test_host_map_resize_matches_oracle():
         assert sh1[1] < 0 and sh1[0] == 0
     with pytest.raises(api.CsmError):
         api.host_map_resize(shape, [5, 5, 4, 9])             # empty box: the reference asserts
+
+
+def test_summary_array_record_bytes_layout():
+    """SummaryArray.record_bytes() lifts the 48-byte csm_result out of each
+    csm_summary (what the ranks all-gather), matching parallel.records_to_bytes."""
+    import ctypes as C
+    from csm_hip import parallel
+    n = 5
+    arr = (L.Summary * n)()
+    for i in range(n):
+        arr[i].raw.found = i % 2
+        arr[i].raw.best_x, arr[i].raw.best_y, arr[i].raw.best_theta = i, -i, 2 * i
+        arr[i].raw.key = 1000 + i
+        arr[i].raw.score = 0.25 * i
+        arr[i].candidates = 7 * i
+    sa = api.SummaryArray(arr)
+    b = sa.record_bytes()
+    assert b.size == n * C.sizeof(L.Result) == n * 48
+    want = parallel.records_to_bytes([api.result_to_dict(arr[i].raw) for i in range(n)]).reshape(-1)
+    assert np.array_equal(b, want)
+    assert sa.total("candidates") == 7 * sum(range(n)) and len(sa) == n
+    assert sa[3]["raw"]["best_theta"] == 6
