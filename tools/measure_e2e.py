@@ -52,6 +52,7 @@ def main():
             init = tuple(np.asarray(case["truth"]) + rng2.uniform(-0.3, 0.3, 3) * (1, 1, 0.2))
             qs.append(dict(map_id=1, geom=case["geom"], angles=case["angles"], ranges=case["ranges"],
                            rel_pose=case["rel_pose"], init_pose=init))
+        qs = ctx.prepare_queries(qs)          # the csm_loop_query[] a C++ caller holds
         ctx.correlative_match_batch(qs, 4.0, 4.0, math.radians(60), 4, 0.0, 0.0)
         t0 = time.perf_counter()
         outs = ctx.correlative_match_batch(qs, 4.0, 4.0, math.radians(60), 4, 0.0, 0.0)
@@ -75,6 +76,7 @@ def main():
     for k, g in grids.items():
         ctx.upload_grid(k, g)
     t_up = time.perf_counter() - t0
+    queries = ctx.prepare_queries(queries)
     t0 = time.perf_counter()
     outs = ctx.bnb_match_batch(queries, 2.5, 2.5, 0.5, 2, 0.55, 0.6)     # builds pyramids
     t_first = time.perf_counter() - t0
