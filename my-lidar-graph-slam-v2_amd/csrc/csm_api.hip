@@ -78,6 +78,7 @@ struct csm_ctx {
     double m_lut_hit = -1.0, m_lut_miss = -1.0;   /* probabilities the update tables were built for */
     bool m_apply_attr = false;
     hipEvent_t m_ev[2] = { nullptr, nullptr };    /* device_us of csm_map_build_info */
+    std::vector<double> stage;                    /* host staging of one scan (angles, ranges) */
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -1400,14 +1401,23 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     if ((rc = ensure(ctx, ctx->unc, 16 + (size_t)kUncCap * 4))) return rc;
     int32_t* col_dev = reinterpret_cast<int32_t*>(ctx->hits.p);
     int32_t* row_dev = col_dev + hn;
-    csm_result* res_dev = reinterpret_cast<csm_result*>(row_dev + hn);
+    /* result record and the uncertified-entry count sit side by side: one read-back */
+    struct Tail {
+        csm_result res;
+        uint32_t n_unc, pad[3];
+    };
+    Tail* tail_dev = reinterpret_cast<Tail*>(row_dev + hn);
+    csm_result* res_dev = &tail_dev->res;
     double* ang_dev = reinterpret_cast<double*>(ctx->scan_dev.p);
     double* rng_dev = ang_dev + n;
-    uint32_t* unc_count = reinterpret_cast<uint32_t*>(ctx->unc.p);
-    uint32_t* unc_list = unc_count + 4;
-    HIP_TRY(ctx, hipMemcpyAsync(ang_dev, scan->angles, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(rng_dev, scan->ranges, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(unc_count, 0, 4, ctx->stream));
+    uint32_t* unc_count = &tail_dev->n_unc;
+    uint32_t* unc_list = reinterpret_cast<uint32_t*>(ctx->unc.p) + 4;
+    /* angles and ranges in one upload */
+    ctx->stage.resize(2 * (size_t)n);
+    std::memcpy(ctx->stage.data(), scan->angles, (size_t)n * 8);
+    std::memcpy(ctx->stage.data() + n, scan->ranges, (size_t)n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(ang_dev, ctx->stage.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(unc_count, 0, 16, ctx->stream));
     ProjJob pj;
     std::memset(&pj, 0, sizeof(pj));
     pj.angles = ang_dev;
@@ -1435,10 +1445,11 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     }
     if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
     if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
-    uint32_t n_unc = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_unc, unc_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&out->raw, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost, ctx->stream));
+    Tail tail;
+    HIP_TRY(ctx, hipMemcpyAsync(&tail, tail_dev, sizeof(tail), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->raw = tail.res;
+    const uint32_t n_unc = tail.n_unc;
     if (n_unc > 0) {
         /* recompute the uncertified entries exactly as the reference does */
         std::vector<int32_t> col(hn), row(hn);
