@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <thread>
@@ -369,13 +370,24 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     return CSM_OK;
 }
 
+/* Dynamic LDS above 64 KB needs the function attribute. It is a driver call and
+ * it belongs to the function on a device, not to a context: one process-wide
+ * table, only ever raised (a smaller value set by another context would make
+ * a larger launch of this one fail). */
 template <typename K>
 int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
 {
-    if (bytes > 64 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)bytes));
+    if (bytes <= 64 * 1024)
+        return CSM_OK;
+    static std::mutex guard;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(guard);
+    size_t& have = granted[{ ctx->device, fn }];
+    if (bytes > have) {
+        HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
     return CSM_OK;
 }
 
