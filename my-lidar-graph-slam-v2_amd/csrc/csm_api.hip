@@ -17,10 +17,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "csm_kernels.hip"
@@ -80,6 +82,7 @@ struct csm_ctx {
     bool m_apply_attr = false;
     hipEvent_t m_ev[2] = { nullptr, nullptr };    /* device_us of csm_map_build_info */
     std::vector<double> stage;                    /* host staging of one scan (angles, ranges) */
+    std::shared_ptr<void> resident_hold;          /* job tables of the last csm_score_windows_dev call */
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -2030,8 +2033,16 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
                            reinterpret_cast<const FinalJob*>(d_fj));
         HIP_TRY(ctx, hipGetLastError());
     }
-    if (resident)
-        return CSM_OK;                      /* asynchronous: the records stay on the device */
+    if (resident) {
+        /* asynchronous: the records stay on the device. The job tables were handed
+         * to hipMemcpyAsync from pageable memory; keep them alive until the next
+         * call instead of relying on the copy having staged them already. */
+        ctx->resident_hold = std::make_shared<
+            std::tuple<std::vector<ProjJob>, std::vector<BinJob>, std::vector<FinalJob>,
+                       std::vector<std::vector<ScoreJob>>>>(std::move(ij), std::move(bj), std::move(fj),
+                                                            std::move(sj));
+        return CSM_OK;
+    }
     std::vector<csm_result> res(nq);
     HIP_TRY(ctx, hipMemcpyAsync(res.data(), d_out, (size_t)nq * sizeof(csm_result),
                                 hipMemcpyDeviceToHost, ctx->stream));
