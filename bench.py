@@ -4,7 +4,7 @@
 Workload at every N: BASELINE.json configs[1] per GPU -- frontend CSM, 1080-beam
 scan over 270 deg, 400x400 grid @ 5 cm, +-2 m / +-30 deg window at 5 cm / 0.5 deg,
 L = 4 (121 x 84 x 84 = 853,776 candidate poses per scan, 2160 algorithmic bytes
-each). One step = SCANS_PER_STEP (32) independent scans, hit indices and grid
+each). One step = SCANS_PER_STEP (64) independent scans, hit indices and grid
 already resident in HBM, scored by one batched launch chain
 (csm_score_windows_dev; CSM_BENCH_MODE=streams scores them one launch chain per
 scan instead). With N > 1 every rank scores its own
@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "my-lidar-graph-slam-v2_amd"))
 
-SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "32"))   # independent scans per step
+SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "64"))   # independent scans per step
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
