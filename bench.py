@@ -1,21 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- candidate poses scored per second by the HIP correlative path.
 
-Workload at every N: BASELINE.json configs[1] per GPU -- frontend CSM, 1080-beam
-scan over 270 deg, 400x400 grid @ 5 cm, +-2 m / +-30 deg window at 5 cm / 0.5 deg,
-L = 4 (121 x 84 x 84 = 853,776 candidate poses per scan, 2160 algorithmic bytes
-each). One step = SCANS_PER_STEP (64) independent scans, hit indices and grid
-already resident in HBM, scored by one batched launch chain
-(csm_score_windows_dev; CSM_BENCH_MODE=streams scores them one launch chain per
-scan instead). With N > 1 every rank scores its own
-scans (weak scaling, no data-path collective) and the per-scan best records
-(48 B) are all-gathered over RCCL at the end of each step, as the loop
-detector's result exchange does.
+N = 1 (default): BASELINE.json configs[1] -- frontend CSM, 1080-beam scan over
+270 deg, 400x400 grid @ 5 cm, +-2 m / +-30 deg window at 5 cm / 0.5 deg, L = 4
+(123 x 84 x 84 = 867,888 candidate poses per scan, 2160 algorithmic bytes
+each). One step = SCANS_PER_STEP (2048) scans, hit indices and grid already
+resident in HBM, scored 64 windows per batched launch chain
+(csm_score_windows_dev), so that the K timed steps last seconds, not
+milliseconds. The same line carries, under "configs", short driver-timed runs
+of configs[2] (256 submaps, pyramid build reported separately), configs[3] at
+N = 1 (2048 submaps on one GPU: the strong-scaling base), configs[4]
+(exhaustive 2000x2000) and the host-inclusive single-query latency of
+configs[1].
+
+N > 1 (default): BASELINE.json configs[3] -- branch-and-bound loop detection,
+2048 candidate submaps sharded in contiguous blocks of 2048 / N queries per
+rank (loop_detector_fpga_parallel.cpp:42-46), one all-gather of the 48-byte
+best records over RCCL per step (":53-56"). Total work is fixed: strong
+scaling. `--workload csm` keeps configs[1] per GPU instead (independent
+replicas, weak scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-"roofline" (dominant kernel = fine scoring kernel, HIP events inside the
-library on its launch stream) and "cpu_baseline" (CPU oracle, 1 core, bounded
-sample; rank 0, N = 1 only).
+"roofline" (dominant kernel = fine / leaf scoring kernel, HIP events inside the
+library on its launch stream) and, at N = 1, "cpu_baseline" (CPU oracle on one
+core and on all cores, bounded samples).
+
+Roofline: the fine kernel gathers from LDS, not from HBM (a 400x400 grid is
+320 KB; measured HBM traffic is < 0.1 % of the algorithmic bytes), so the bound
+reported is the LDS read rate: achieved = 4 B x (cell entries x candidates) per
+launch / launch time against 256 B/clk/CU x 256 CUs x 2.4 GHz. The metric's own
+figure (2 B x beams x candidates against 8 TB/s of HBM) is kept as
+"logical_hbm_frac"; it exceeds 1 because those bytes never leave the chip.
 """
 import argparse
 import json
@@ -28,8 +43,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "my-lidar-graph-slam-v2_amd"))
 
-SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "64"))   # independent scans per step
+WINDOWS_PER_LAUNCH = 64
+SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "2048"))     # scans per step
+DISTINCT_SCANS = int(os.environ.get("CSM_BENCH_DISTINCT", "256"))    # different scans generated
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# MI355X_MICROARCH.md, LDS: 64 banks x 4 B per clock per CU (ds_read_b64 / b128
+# rate), 256 CUs, 2.4 GHz max clock. ds_read_b32 reaches half of it.
+LDS_PEAK_GBS = 256.0 * 256 * 2.4
+METRIC = "candidate poses scored/sec (CSM+BnB), 1/2/4/8 GPU; % HBM roofline"
+N_BEAMS = 1080
+LOOP_PARAMS = (2.5, 2.5, 0.5, 2, 0.55, 0.6)    # launcher_settings_default.json:130-131, 143-146
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_fine_traffic.json")
 
 
 def make_workload(rank, n_scans):
@@ -42,7 +66,7 @@ def make_workload(rank, n_scans):
     scans = []
     for i in range(n_scans):
         truth = (0.5 * (rng.rand() - 0.5), 0.5 * (rng.rand() - 0.5), 0.3 * (rng.rand() - 0.5))
-        angles, ranges = synth.cast_scan(segs, truth, n_beams=1080, fov=1.5 * math.pi,
+        angles, ranges = synth.cast_scan(segs, truth, n_beams=N_BEAMS, fov=1.5 * math.pi,
                                          max_range=5.7296)
         init = (truth[0] + 0.31 * (rng.rand() - 0.5), truth[1] + 0.31 * (rng.rand() - 0.5),
                 truth[2] + 0.1 * (rng.rand() - 0.5))
@@ -54,80 +78,169 @@ def make_workload(rank, n_scans):
     return dict(grid=grid, geom=geom, scans=scans, params=(rx, ry, rt, L))
 
 
+def cell_entries(col, row, rows, cols, x_lo, y_lo, x_hi, y_hi, max_mult=15):
+    """Distinct (theta, cell) pairs a window's beams land on, counted the way
+    the binning kernel forms its entries (a cell with more than 15 beams is
+    split; beams that cannot touch the grid for any candidate are dropped):
+    the LDS gathers one candidate needs."""
+    import numpy as np
+    nt = col.shape[0]
+    total = 0
+    for t in range(nt):
+        r, c = row[t].astype(np.int64), col[t].astype(np.int64)
+        ok = (r + y_hi >= 0) & (r <= rows - 1 - y_lo) & (c + x_hi >= 0) & (c <= cols - 1 - x_lo)
+        key = (r[ok] + (1 << 20)) * (1 << 22) + (c[ok] + (1 << 20))
+        _, cnt = np.unique(key, return_counts=True)
+        total += int(((cnt + max_mult - 1) // max_mult).sum())
+    return total
+
+
 def pmc_traffic():
-    """HBM bytes per fine-kernel launch from the committed PMC passes
-    (profiles/r01_pmc_fine_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    in separate runs of this same bench, FETCH_SIZE doubled per the gfx950
-    note). A live bench run cannot collect counters itself; null when the file
-    is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fine_traffic.json")
+    """HBM bytes per fine-kernel launch from the committed PMC passes (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command,
+    FETCH_SIZE doubled per the gfx950 note). A live bench run cannot collect
+    counters itself, so this is a committed measurement, labelled as such;
+    (None, None) when the file is absent."""
     try:
-        with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        src = "%s (committed; kernel %s, %s windows per launch, library %s)" % (
+            os.path.relpath(PMC_FILE, ROOT), d.get("kernel", "?"), d.get("windows_per_launch", "?"),
+            d.get("library_version", "?"))
+        return float(d["hbm_bytes_per_launch"]), src
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
-def cpu_baseline(wl, budget_s=12.0, max_scans=400):
-    """The CPU oracle (literal ScanMatcherCorrelative sweep with pruning), one
-    core, on the first scans of the same workload."""
+def cpu_baseline(wl, budget_s=10.0, max_scans=2000):
+    """The CPU oracle (literal ScanMatcherCorrelative sweep with pruning) on the
+    first scans of the same workload: one core (the reference is
+    single-threaded on this path) and OpenMP over theta on all host cores."""
     from oracle import oracle as O
     rx, ry, rt, L = wl["params"]
     coarse = O.boxmax(wl["grid"], L)
-    t0 = time.time()
-    n_done, cands, fine = 0, 0, 0
-    for i in range(max_scans):
-        sc = wl["scans"][i % len(wl["scans"])]
-        case = dict(grid=wl["grid"], geom=wl["geom"], angles=sc["angles"], ranges=sc["ranges"],
-                    rel_pose=sc["rel_pose"], init_pose=sc["init_pose"])
-        r = O.csm(case, rx, ry, rt, L, coarse=coarse)
-        wx, wy, wt = r["winX"], r["winY"], r["winT"]
-        nx = -(-(2 * wx + 1) // L) * L
-        ny = -(-(2 * wy + 1) // L) * L
-        cands += (2 * wt + 1) * nx * ny
-        fine += r["fineEvaluated"]
-        n_done += 1
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    return dict(value=cands / dt, unit="candidate poses/s", cores=1, kind="port",
+
+    def run(fn):
+        t0 = time.time()
+        n_done, cands, fine, threads = 0, 0, 0, 1
+        for i in range(max_scans):
+            sc = wl["scans"][i % len(wl["scans"])]
+            case = dict(grid=wl["grid"], geom=wl["geom"], angles=sc["angles"], ranges=sc["ranges"],
+                        rel_pose=sc["rel_pose"], init_pose=sc["init_pose"])
+            r = fn(case, rx, ry, rt, L, coarse=coarse)
+            threads = r.get("threads", 1)
+            wx, wy, wt = r["winX"], r["winY"], r["winT"]
+            nx = -(-(2 * wx + 1) // L) * L
+            ny = -(-(2 * wy + 1) // L) * L
+            cands += (2 * wt + 1) * nx * ny
+            fine += r["fineEvaluated"]
+            n_done += 1
+            if time.time() - t0 > budget_s:
+                break
+        dt = time.time() - t0
+        return n_done, cands / dt, fine / dt, dt, threads
+
+    O.csm_omp(dict(grid=wl["grid"], geom=wl["geom"], angles=wl["scans"][0]["angles"],
+                   ranges=wl["scans"][0]["ranges"], rel_pose=(0.0, 0.0, 0.0),
+                   init_pose=wl["scans"][0]["init_pose"]), rx, ry, rt, L, coarse=coarse)   # thread pool up
+    n1, v1, f1, d1, _ = run(O.csm)
+    nn, vn, fn_, dn, threads = run(O.csm_omp)
+    return dict(value=v1, unit="candidate poses/s", cores=1, kind="port",
                 sample="%d scan(s) of the same workload, %.1f s wall, coarse pruning on: "
                        "%.3g window poses/s nominal, %.3g fully evaluated fine poses/s"
-                       % (n_done, dt, cands / dt, fine / dt))
+                       % (n1, d1, v1, f1),
+                all_cores=dict(value=vn, unit="candidate poses/s", cores=threads, kind="port",
+                               sample="OpenMP over theta, %d threads, %d scan(s), %.1f s wall: %.3g window "
+                                      "poses/s nominal, %.3g fully evaluated fine poses/s"
+                                      % (threads, nn, dn, vn, fn_)))
 
 
-def run_loop_workload(args, rank, world, dev, dev_index, rehearse):
-    """configs[2] per GPU (configs[3] at 8 GPUs): one 1080-beam scan against 256
-    candidate submaps (400x400 @ 5 cm, 3-level pyramids), 2.5 m x 2.5 m x 0.5 rad,
-    thresholds 0.55 / 0.6. Maps and pyramids resident; a step = one
-    csm_bnb_match_batch call on this rank's 256 queries + the all-gather of the
-    48-byte records."""
+# ------------------------------------------------------------------ loop detection (configs[2] / [3])
+
+def make_loop_queries(ctx, lo, hi):
+    """Submaps lo..hi-1 of the 2048-submap batch (seeds = query numbers, so every
+    rank builds exactly its own block), uploaded under map id = query number."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from csm_hip import api, parallel, synth
-    n_sub = 256
-    ctx = api.Context(dev_index)
-    rng = np.random.RandomState(77 + rank)
+    from csm_hip import synth
     queries = []
-    for i in range(n_sub):
-        c = synth.csm_case(100000 * rank + i, n_beams=1080, fov=1.5 * math.pi)
+    t_up = 0.0
+    for i in range(lo, hi):
+        c = synth.csm_case(100000 + i, n_beams=N_BEAMS, fov=1.5 * math.pi)
+        rng = np.random.RandomState(77000 + i)
+        t0 = time.perf_counter()
         ctx.upload_grid(i, c["grid"])
+        t_up += time.perf_counter() - t0
         init = tuple(np.asarray(c["truth"]) + rng.uniform(-0.6, 0.6, 3) * (1, 1, 0.15))
         queries.append(dict(map_id=i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
                             rel_pose=(0.0, 0.0, 0.0), init_pose=init))
-    params = (2.5, 2.5, 0.5, 2, 0.55, 0.6)
-    # the query array is marshalled once, as a C++ caller holds it (csm_loop_query[])
+    return queries, t_up
+
+
+def loop_roofline(leaves, fine_ms, fine_n, entries_per_leaf_query=None):
+    alg = 2.0 * N_BEAMS * leaves
+    avg = fine_ms / max(1, fine_n) * 1e-3
+    d = {"bound": "lds", "kernel": "k_score_batch (leaf level)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
+         "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": None,
+         "logical_hbm_gbs": alg / avg / 1e9 if avg > 0 else 0.0,
+         "logical_hbm_frac": alg / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0}
+    if entries_per_leaf_query is not None and avg > 0:
+        d["achieved"] = 4.0 * entries_per_leaf_query / avg / 1e9
+        d["frac"] = d["achieved"] / LDS_PEAK_GBS
+    else:
+        d["achieved"], d["frac"] = None, None
+    return d
+
+
+def loop_gathers(queries, prm):
+    """4-byte LDS gathers one leaf pass over `queries` needs (cell entries x leaves)."""
+    from csm_hip import api
+    rx, ry, rt, H = prm[:4]
+    total = 0
+    stride = max(1, len(queries) // 64)          # a sample of <= ~64 queries, scaled up
+    sample = queries[::stride]
+    for q in sample:
+        sx, sy, st = api.host_search_step(q["geom"][0], q["ranges"])
+        wx, wy, wt = api.host_window(rx, sx), api.host_window(ry, sy), api.host_window(rt, st)
+        big = 1 << H
+        nx = -(-(2 * wx + 1) // big) * big
+        ny = -(-(2 * wy + 1) // big) * big
+        col, row = api.host_project(q["geom"], q["init_pose"], st, wt, q["angles"], q["ranges"])
+        e = cell_entries(col, row, 400, 400, -wx, -wy, -wx + nx - 1, -wy + ny - 1)
+        total += e * nx * ny
+    return total * len(queries) / len(sample)
+
+
+def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_total, strong):
+    """Branch-and-bound loop detection, n_total candidate submaps (400x400 @ 5 cm,
+    3-level grids, one 1080-beam scan each), 2.5 m x 2.5 m x 0.5 rad, thresholds
+    0.55 / 0.6, sharded in contiguous blocks over the ranks. Maps and pyramids
+    resident; a step = one csm_bnb_match_batch call on this rank's block + ONE
+    all-gather of the 48-byte records (device buffers, RCCL)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from csm_hip import api, parallel
+    lo, hi = parallel.shard_bounds(n_total, rank, world)
+    block = -(-n_total // world)
+    ctx = api.Context(dev_index)
+    ctx.set_stream(stream.cuda_stream)
+    queries, _ = make_loop_queries(ctx, lo, hi)
     prepared = ctx.prepare_queries(queries)
+    rec_bytes = parallel.RECORD_BYTES
+    send = torch.zeros(block * rec_bytes, dtype=torch.uint8, device=dev)
+    recv = torch.zeros(world * block * rec_bytes, dtype=torch.uint8, device=dev)
 
     def step():
-        outs = ctx.bnb_match_batch(prepared, *params, as_records=True)
+        outs = ctx.bnb_match_batch(prepared, *LOOP_PARAMS, as_records=True)
         if world > 1:
-            rec = torch.from_numpy(outs.record_bytes())
-            if not rehearse:
-                rec = rec.to(dev)
-            out = torch.zeros(world * rec.numel(), dtype=torch.uint8, device=rec.device)
-            dist.all_gather_into_tensor(out, rec)
+            ctx.copy_last_batch_records(send.data_ptr())      # device to device, on `stream`
+            if rehearse:
+                host = send.cpu()
+                out = torch.zeros(world * host.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, host)
+                recv.copy_(out)
+            else:
+                dist.all_gather_into_tensor(recv, send)
         return outs
 
     def fence():
@@ -136,47 +249,182 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(1, args.warmup)):
-        outs = step()
-    fence()
-    ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
-    ctx.reset_kernel_timing()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs = step()
-    fence()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(stream):
+        for _ in range(max(1, args.warmup)):
+            outs = step()
+        fence()
+        ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
+        ctx.reset_kernel_timing()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            outs = step()
+        fence()
+        dt = time.perf_counter() - t0
     ctx.enable_kernel_timing(False)
     fine_ms, fine_n = ctx.kernel_time("score_fine")
+    leaves_local = outs.total("candidates")
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
+        tt = torch.tensor([dt, float(leaves_local)], dtype=torch.float64, device=None if rehearse else dev)
+        tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt, leaves = float(tmax[0].item()), int(tt[1].item())
+        # every rank must now hold every record, in query order
+        allrec = recv.cpu().numpy().reshape(world, block, rec_bytes)
+        mine = np.frombuffer(outs.record_bytes(), np.uint8).reshape(-1, rec_bytes)
+        assert np.array_equal(allrec[rank, :hi - lo], mine), "gathered block differs from the local records"
+        found = 0
+        for r in range(world):
+            a, b = parallel.shard_bounds(n_total, r, world)
+            found += int(allrec[r, :b - a, :4].copy().view(np.int32).sum())
+    else:
+        leaves = leaves_local
+        found = sum(o["pose_found"] for o in outs)
     if rank == 0:
-        leaves = outs.total("candidates")
-        outs = list(outs)
-        alg = 2.0 * 1080 * leaves
-        avg = fine_ms / max(1, fine_n) * 1e-3
+        rl = loop_roofline(leaves_local, fine_ms, fine_n, loop_gathers(queries, LOOP_PARAMS))
         print(json.dumps({
-            "metric": "candidate poses scored/sec (CSM+BnB), 1/2/4/8 GPU; % HBM roofline",
-            "value": leaves * args.steps * world / dt, "unit": "candidate poses/s",
+            "metric": METRIC, "value": leaves * args.steps / dt, "unit": "candidate poses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "configs[2] per GPU: branch-and-bound loop detection, 1 scan vs 256 "
-                                   "submaps, 3-level grids, 2.5 m x 2.5 m x 0.5 rad, thresholds 0.55/0.6; "
-                                   "host-inclusive batch call (scans in host memory, query array marshalled once, maps resident)",
-                       "leaves_per_step_per_gpu": leaves, "found": sum(o["pose_found"] for o in outs),
-                       "flagged": sum(1 for o in outs if o["raw"]["flags"]),
-                       "parallelism": "queries sharded per GPU, all-gather of 48-B records"
+            "config": {"workload": "configs[%d]: branch-and-bound loop detection, %d candidate submaps "
+                                   "(400x400@5cm, 3-level grids, 1080 beams), 2.5 m x 2.5 m x 0.5 rad, "
+                                   "thresholds 0.55/0.6; host-inclusive batch call per rank (scans in host "
+                                   "memory, query array marshalled once, maps and pyramids resident)"
+                                   % (3 if strong else 2, n_total),
+                       "queries_total": n_total, "queries_per_rank": hi - lo,
+                       "leaves_per_step": leaves, "found": found,
+                       "parallelism": "contiguous query blocks per GPU, one all-gather of 48-B records "
+                                      "per step (%s)" % ("gloo rehearsal" if rehearse else "RCCL")
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_score_batch (leaf level)",
-                         "achieved": alg / avg / 1e9 if avg > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": alg / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0,
-                         "traffic": None, "avg_launch_us": avg * 1e6, "launches": fine_n},
+            "roofline": rl,
         }), flush=True)
     ctx.close()
 
+
+def measure_loop_config(dev_index, n_sub, steps=5):
+    """configs[2] (n_sub = 256) or configs[3] at N = 1 (2048) as a short run:
+    upload, pyramid build (timed on its own), then `steps` batch calls."""
+    import torch
+    from csm_hip import api
+    ctx = api.Context(dev_index)
+    t0 = time.perf_counter()
+    queries, t_up = make_loop_queries(ctx, 0, n_sub)
+    t_gen = time.perf_counter() - t0 - t_up
+    prepared = ctx.prepare_queries(queries)
+    H = LOOP_PARAMS[3]
+    ctx.synchronize()
+    ctx.enable_kernel_timing(True)
+    ctx.reset_kernel_timing()
+    t0 = time.perf_counter()
+    ctx.build_pyramids(list(range(n_sub)), [1 << h for h in range(H + 1)])
+    ctx.synchronize()
+    t_pyr = time.perf_counter() - t0
+    box_ms, box_n = ctx.kernel_time("boxmax")
+    ctx.enable_kernel_timing(False)
+    t0 = time.perf_counter()
+    outs = ctx.bnb_match_batch(prepared, *LOOP_PARAMS, as_records=True)      # first call
+    t_first = time.perf_counter() - t0
+    ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
+    ctx.reset_kernel_timing()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        outs = ctx.bnb_match_batch(prepared, *LOOP_PARAMS, as_records=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.enable_kernel_timing(False)
+    fine_ms, fine_n = ctx.kernel_time("score_fine")
+    leaves = outs.total("candidates")
+    found = sum(1 for o in outs if o["pose_found"])
+    flagged = sum(1 for o in outs if o["raw"]["flags"])
+    rl = loop_roofline(leaves, fine_ms, fine_n, loop_gathers(queries, LOOP_PARAMS))
+    ctx.close()
+    return {"workload": "configs[%d]%s: 1080-beam scans vs %d candidate submaps, 3-level grids, 2.5 m x 2.5 m x "
+                        "0.5 rad, thresholds 0.55/0.6" % (2 if n_sub == 256 else 3,
+                                                          "" if n_sub == 256 else " on ONE GPU (strong-scaling base)",
+                                                          n_sub),
+            "value": leaves / dt, "unit": "candidate poses/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "leaves_per_step": leaves, "found": found, "flagged": flagged,
+            "pyramid_build_ms": t_pyr * 1e3, "pyramid_build_kernel_ms": box_ms, "pyramid_launches": box_n,
+            "upload_ms": t_up * 1e3, "host_generation_s": t_gen, "first_call_ms": t_first * 1e3,
+            "end_to_end_value": leaves / (dt + t_pyr), "end_to_end_note":
+                "one search step + the pyramid build of all %d maps (paid once per map in the "
+                "reference too, loop_detector_branch_bound.cpp:83-89)" % n_sub,
+            "roofline": rl}
+
+
+def measure_config5(dev_index, runs=2):
+    """configs[4]: exhaustive global CSM, 2000x2000 @ 2.5 cm, +-10 m / +-180 deg at
+    2.5 cm / 0.25 deg, 1080 beams, L = 4: 9.3e8 candidate poses per query."""
+    import torch
+    from csm_hip import api, synth
+    case = synth.csm_case(7, rows=2000, cols=2000, res=0.025, n_beams=N_BEAMS, fov=1.5 * math.pi,
+                          max_range=5.7296, init_error=(3.1, -2.7, 1.3), n_boxes=10)
+    ctx = api.Context(dev_index)
+    t0 = time.perf_counter()
+    ctx.upload_grid(5, case["grid"])
+    t_up = time.perf_counter() - t0
+    args = (5, case["geom"], case["angles"], case["ranges"], case["rel_pose"], case["init_pose"],
+            20.0, 20.0, 2 * math.pi, 4, 0.0, 0.0)
+    out = ctx.correlative_match(*args)          # builds box-max(4), warms up
+    ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
+    ctx.reset_kernel_timing()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        out = ctx.correlative_match(*args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / runs
+    ctx.enable_kernel_timing(False)
+    fine_ms, fine_n = ctx.kernel_time("score_fine")
+    cands = out["candidates"]
+    avg = fine_ms / max(1, fine_n) * 1e-3
+    wt = out["win_theta"]
+    col, row = api.host_project(case["geom"], out["sensor_pose"], out["step_theta"], wt, case["angles"],
+                                case["ranges"])
+    nx = ny = 804
+    ent = cell_entries(col, row, 2000, 2000, -out["win_x"], -out["win_y"], -out["win_x"] + nx - 1,
+                       -out["win_y"] + ny - 1)
+    lds = 4.0 * ent / (2 * wt + 1) * cands
+    ctx.close()
+    return {"workload": "configs[4]: exhaustive global CSM, 2000x2000@2.5cm, +-10 m/+-180 deg at 2.5 cm/0.25 deg, "
+                        "1080 beams, L=4; host-inclusive csm_correlative_match (projection on device)",
+            "value": cands / dt, "unit": "candidate poses/s", "ms_per_query": dt * 1e3, "runs": runs,
+            "candidates": cands, "found": out["pose_found"], "upload_ms": t_up * 1e3,
+            "roofline": {"bound": "lds", "kernel": "k_score (fine level)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
+                         "achieved": lds / avg / 1e9 if avg > 0 else None,
+                         "frac": lds / avg / 1e9 / LDS_PEAK_GBS if avg > 0 else None,
+                         "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": None,
+                         "logical_hbm_gbs": 2.0 * N_BEAMS * cands / avg / 1e9 if avg > 0 else None,
+                         "logical_hbm_frac": 2.0 * N_BEAMS * cands / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else None}}
+
+
+def measure_config2_latency(dev_index, wl, reps=30):
+    """What one frontend caller sees: csm_correlative_match per scan, scan in host
+    memory, projection on the device, summary back on the host."""
+    from csm_hip import api
+    rx, ry, rt, L = wl["params"]
+    ctx = api.Context(dev_index)
+    ctx.upload_grid(1, wl["grid"])
+    samples = []
+    for i in range(reps + 3):
+        sc = wl["scans"][i % len(wl["scans"])]
+        t0 = time.perf_counter()
+        out = ctx.correlative_match(1, wl["geom"], sc["angles"], sc["ranges"], sc["rel_pose"],
+                                    sc["init_pose"], rx, ry, rt, L, 0.0, 0.0)
+        samples.append(time.perf_counter() - t0)
+    ctx.close()
+    samples = sorted(samples[3:])
+    med = samples[len(samples) // 2]
+    return {"workload": "configs[1], one query per call: csm_correlative_match, host-inclusive "
+                        "(17 KB up, projection + search on device, 48-B record back)",
+            "latency_ms_median": med * 1e3, "latency_ms_min": samples[0] * 1e3,
+            "value": out["candidates"] / med, "unit": "candidate poses/s", "reps": reps}
+
+
+# ------------------------------------------------------------------ map workload (not the BASELINE metric)
 
 def run_map_workload(args, rank, world, dev, dev_index, rehearse):
     """SURVEY 8(f) rank 4, the frontend cycle: a step = rebuild the latest map
@@ -283,24 +531,209 @@ def run_map_workload(args, rank, world, dev, dev_index, rehearse):
     ctx.close()
 
 
+# ------------------------------------------------------------------ frontend CSM (configs[1])
+
+def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from csm_hip import api
+
+    n_chunks = max(1, SCANS_PER_STEP // WINDOWS_PER_LAUNCH)
+    n_distinct = max(WINDOWS_PER_LAUNCH, min(DISTINCT_SCANS, n_chunks * WINDOWS_PER_LAUNCH))
+    n_distinct -= n_distinct % WINDOWS_PER_LAUNCH
+    scans_per_step = n_chunks * WINDOWS_PER_LAUNCH
+    wl = make_workload(rank, n_distinct)
+    rx, ry, rt, L = wl["params"]
+    ctx = api.Context(dev_index)
+    # a non-default torch stream: csm_set_stream(NULL) would mean "the context's
+    # own stream", and the collectives below must be ordered against the scoring
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload_grid(1, wl["grid"])
+    ctx.build_pyramid(1, [1, L])
+
+    windows, cols, rows_, cands = [], [], [], []
+    for sc in wl["scans"]:
+        wx, wy, wt = sc["win"]
+        windows.append(ctx.make_window(2 * wt + 1, N_BEAMS, wx, wy, L, 1, api.host_min_known(N_BEAMS, 0.0), 0.0))
+        cols.append(torch.from_numpy(sc["col"]).to(dev))
+        rows_.append(torch.from_numpy(sc["row"]).to(dev))
+        nx = -(-(2 * wx + 1) // L) * L
+        ny = -(-(2 * wy + 1) // L) * L
+        cands.append((2 * wt + 1) * nx * ny)
+    rec_bytes = 48
+    results = torch.zeros(scans_per_step * rec_bytes, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * scans_per_step * rec_bytes, dtype=torch.uint8, device=dev)
+    n_batches = n_distinct // WINDOWS_PER_LAUNCH
+    prepared = []
+    for b in range(n_batches):
+        sl = slice(b * WINDOWS_PER_LAUNCH, (b + 1) * WINDOWS_PER_LAUNCH)
+        prepared.append(ctx.prepare_windows([1] * WINDOWS_PER_LAUNCH, windows[sl],
+                                            [c.data_ptr() for c in cols[sl]],
+                                            [r.data_ptr() for r in rows_[sl]]))
+    cands_per_batch = [sum(cands[b * WINDOWS_PER_LAUNCH:(b + 1) * WINDOWS_PER_LAUNCH]) for b in range(n_batches)]
+    cands_per_step = sum(cands_per_batch[k % n_batches] for k in range(n_chunks))
+
+    def step():
+        for k in range(n_chunks):
+            ctx.score_windows_dev(prepared[k % n_batches],
+                                  results.data_ptr() + k * WINDOWS_PER_LAUNCH * rec_bytes)
+        if world > 1:
+            if rehearse:
+                host = results.cpu()
+                out = torch.zeros(world * host.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, host)
+                gathered.copy_(out)
+            else:
+                dist.all_gather_into_tensor(gathered, results)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        # events around the dominant kernel only inside the timed region; the
+        # other kernels are timed in a short extra pass afterwards
+        ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
+        ctx.reset_kernel_timing()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        ctx.enable_kernel_timing(False)
+        fine_ms, fine_n = ctx.kernel_time("score_fine")
+        ctx.lib.csm_enable_kernel_timing(ctx._ctx, 1)
+        ctx.reset_kernel_timing()
+        step()
+        fence()
+        ctx.enable_kernel_timing(False)
+    others = {}
+    for name in ("score_coarse", "bin", "finalize"):
+        ms, n = ctx.kernel_time(name)
+        others[name] = ms / max(1, n) * 1e3
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # this rank's slice of the gathered buffer must be its own records
+        mine = gathered[rank * results.numel():(rank + 1) * results.numel()]
+        assert torch.equal(mine, results), "all-gather read the records before they were written"
+
+    # sanity: every scan found a pose and the record decodes
+    rec = np.frombuffer(results.cpu().numpy().tobytes(), dtype=np.int32).reshape(scans_per_step, 12)
+    n_found = int(rec[:, 0].sum())
+
+    if rank == 0:
+        total = cands_per_step * args.steps * world
+        value = total / dt
+        cands_per_launch = cands_per_step / n_chunks
+        alg_bytes = 2.0 * N_BEAMS * cands_per_launch
+        avg_fine_s = (fine_ms / max(1, fine_n)) * 1e-3
+        # LDS gathers one launch needs: cell entries x candidates, summed over its windows
+        gathers = 0
+        for i in range(WINDOWS_PER_LAUNCH):
+            sc = wl["scans"][i]
+            wx, wy, wt = sc["win"]
+            nx = -(-(2 * wx + 1) // L) * L
+            ny = -(-(2 * wy + 1) // L) * L
+            gathers += cell_entries(sc["col"], sc["row"], 400, 400, -wx, -wy, -wx + nx - 1, -wy + ny - 1) * nx * ny
+        lds_bytes = 4.0 * gathers
+        achieved = lds_bytes / avg_fine_s / 1e9 if avg_fine_s > 0 else 0.0
+        logical = alg_bytes / avg_fine_s / 1e9 if avg_fine_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic()
+        out = {
+            "metric": METRIC,
+            "value": value,
+            "unit": "candidate poses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",   # uint16 cells, exact u32/u64 integer sums; f64 replay of the winner
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: frontend CSM, 1080-beam scan, 400x400@5cm grid, "
+                            "+-2 m/+-30 deg window at 5 cm/0.5 deg, L=4",
+                "scans_per_step": scans_per_step,
+                "distinct_scans": n_distinct,
+                "mode": "csm_score_windows_dev, %d windows per launch chain, %d chains per step"
+                        % (WINDOWS_PER_LAUNCH, n_chunks),
+                "candidates_per_scan": cands_per_step / scans_per_step,
+                "beams": N_BEAMS,
+                "parallelism": "independent replicas per GPU, all-gather of 48-B best records" if world > 1
+                               else "single GPU",
+                "poses_found": n_found,
+            },
+            "roofline": {
+                "bound": "lds",
+                "kernel": "k_score_batch (fine level, %d windows per launch)" % WINDOWS_PER_LAUNCH,
+                "achieved": achieved,
+                "peak": LDS_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / LDS_PEAK_GBS,
+                "note": "LDS gather bytes (4 B x cell entries x candidates) per launch / launch time vs "
+                        "256 B/clk/CU x 256 CUs x 2.4 GHz; the grid window lives in LDS, HBM is not the bound",
+                "lds_gathers_per_launch": gathers,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "hbm_frac_measured": (traffic / avg_fine_s / 1e9 / HBM_PEAK_GBS)
+                                     if traffic is not None and avg_fine_s > 0 else None,
+                "logical_hbm_gbs": logical,
+                "logical_hbm_frac": logical / HBM_PEAK_GBS,
+                "avg_launch_us": avg_fine_s * 1e6,
+                "launches": fine_n,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "other_kernels_avg_us": others,
+            },
+        }
+        ctx.close()
+        if world == 1 and not args.no_configs:
+            cfgs = {}
+            wanted = os.environ.get("CSM_BENCH_CONFIGS",
+                                    "config2_single_query,config3,config4_one_gpu,config5").split(",")
+            for name, fn in (("config2_single_query", lambda: measure_config2_latency(dev_index, wl)),
+                             ("config3", lambda: measure_loop_config(dev_index, 256)),
+                             ("config4_one_gpu", lambda: measure_loop_config(dev_index, 2048, steps=3)),
+                             ("config5", lambda: measure_config5(dev_index))):
+                if name not in wanted:
+                    continue
+                try:
+                    cfgs[name] = fn()
+                except Exception as e:          # a side measurement must not lose the headline line
+                    cfgs[name] = {"error": repr(e)}
+            out["configs"] = cfgs
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    else:
+        ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true",
-                    help="also measure the host-inclusive batched detector entry on the same scans "
-                         "(off by default: its launches share the dominant kernel's symbol and would "
-                         "mix into a profile of this command)")
-    ap.add_argument("--no-extras", action="store_true", help="(default; kept for old command lines)")
-    ap.add_argument("--workload", choices=["csm", "loop", "map"], default="csm",
-                    help="csm (default): BASELINE configs[1]; loop: configs[2]/[3], 256 candidate "
-                         "submaps per GPU through the branch-and-bound batch + all-gather; map: the "
-                         "frontend cycle (latest-map build from 10 scans + match), not the BASELINE metric")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short side runs of configs[2], [3] at N = 1, [4] and the single-query latency")
+    ap.add_argument("--workload", choices=["auto", "csm", "loop", "loop4", "map"], default="auto",
+                    help="auto (default): csm at N = 1, loop4 at N > 1. csm: BASELINE configs[1] per GPU "
+                         "(replicas). loop: configs[2], 256 candidate submaps per GPU. loop4: configs[3], 2048 "
+                         "submaps sharded over the ranks (strong scaling) + all-gather. map: the frontend "
+                         "cycle (latest-map build from 10 scans + match), not the BASELINE metric")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -324,219 +757,20 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()          # file-locked: ranks take turns, later ones find it built
-    from csm_hip import api, _lib
 
-    if args.workload in ("loop", "map"):
-        (run_loop_workload if args.workload == "loop" else run_map_workload)(
-            args, rank, world, dev, dev_index, rehearse)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    wl = make_workload(rank, SCANS_PER_STEP)
-    rx, ry, rt, L = wl["params"]
-    # The scans of a step are independent: they alternate between N_STREAMS
-    # matcher contexts (one HIP stream each), so one scan's small kernels (bin,
-    # arg-max, finalize: a few workgroups each) run beside another scan's
-    # full-chip scoring kernel instead of leaving the chip idle.
-    # CSM_BENCH_MODE=batch (default): the step's scans go through the batched launch
-    # chain in one call (csm_score_windows_dev); =streams: one launch chain per scan
-    # (csm_score_window_dev), alternating between N_STREAMS contexts.
-    batch_mode = os.environ.get("CSM_BENCH_MODE", "batch") == "batch"
-    n_streams = 1 if batch_mode else max(1, min(SCANS_PER_STEP, int(os.environ.get("CSM_BENCH_STREAMS", "2"))))
-    stream = torch.cuda.current_stream(dev)
-    side_streams = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
-    ctxs = []
-    for k in range(n_streams):
-        c = api.Context(dev_index)
-        c.set_stream((stream if k == 0 else side_streams[k - 1]).cuda_stream)
-        c.upload_grid(1, wl["grid"])
-        c.build_pyramid(1, [1, L])
-        ctxs.append(c)
-    ctx = ctxs[0]
-
-    n_beams = 1080
-    windows, cols, rows_ = [], [], []
-    cands_per_step = 0
-    for sc in wl["scans"]:
-        wx, wy, wt = sc["win"]
-        w = ctx.make_window(2 * wt + 1, n_beams, wx, wy, L, 1, api.host_min_known(n_beams, 0.0), 0.0)
-        windows.append(w)
-        cols.append(torch.from_numpy(sc["col"]).to(dev))
-        rows_.append(torch.from_numpy(sc["row"]).to(dev))
-        nx = -(-(2 * wx + 1) // L) * L
-        ny = -(-(2 * wy + 1) // L) * L
-        cands_per_step += (2 * wt + 1) * nx * ny
-    rec_bytes = 48
-    results = torch.zeros(SCANS_PER_STEP * rec_bytes, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * SCANS_PER_STEP * rec_bytes, dtype=torch.uint8, device=dev)
-
-    prepared = ctx.prepare_windows([1] * SCANS_PER_STEP, windows, [c.data_ptr() for c in cols],
-                                   [r.data_ptr() for r in rows_])
-
-    def step():
-        if batch_mode:
-            ctx.score_windows_dev(prepared, results.data_ptr())
-        else:
-            for s2 in side_streams:
-                s2.wait_stream(stream)       # the previous step's all-gather has read `results`
-            for i in range(SCANS_PER_STEP):
-                ctxs[i % n_streams].score_window_dev(1, windows[i], cols[i].data_ptr(), rows_[i].data_ptr(),
-                                                     results.data_ptr() + i * rec_bytes)
-            for s2 in side_streams:
-                stream.wait_stream(s2)
-        if world > 1:
-            if rehearse:
-                host = results.cpu()
-                out = torch.zeros(world * host.numel(), dtype=torch.uint8)
-                dist.all_gather_into_tensor(out, host)
-            else:
-                dist.all_gather_into_tensor(gathered, results)
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # events around the dominant kernel only inside the timed region; the
-    # other kernels are timed in a short extra pass afterwards
-    for c in ctxs:
-        c.lib.csm_enable_kernel_timing(c._ctx, 2)
-        c.reset_kernel_timing()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-
-    def timer_sum(name):
-        ms = n = 0
-        for c in ctxs:
-            a, b = c.kernel_time(name)
-            ms, n = ms + a, n + b
-        return ms, n
-    for c in ctxs:
-        c.enable_kernel_timing(False)
-    fine_ms, fine_n = timer_sum("score_fine")
-    for c in ctxs:
-        c.lib.csm_enable_kernel_timing(c._ctx, 1)
-        c.reset_kernel_timing()
-    step()
-    fence()
-    for c in ctxs:
-        c.enable_kernel_timing(False)
-    coarse_ms, coarse_n = timer_sum("score_coarse")
-    bin_ms, bin_n = timer_sum("bin")
-    fin_ms, fin_n = timer_sum("finalize")
-    arg_ms, arg_n = timer_sum("argmax")
-
-    # extra (not `value`): the same scans through the batched detector entry
-    # (csm_correlative_match_batch: scans arrive as host arrays, projection on
-    # the device, 64 queries per call) -- what LoopDetectorCorrelative-style
-    # callers get when queries are independent
-    batched = None
-    if rank == 0 and args.extras:
-        qs = []
-        for rep in range(max(1, 64 // SCANS_PER_STEP)):
-            for sc in wl["scans"]:
-                init = (sc["init_pose"][0] + 0.01 * rep, sc["init_pose"][1] - 0.01 * rep, sc["init_pose"][2])
-                qs.append(dict(map_id=1, geom=wl["geom"], angles=sc["angles"], ranges=sc["ranges"],
-                               rel_pose=sc["rel_pose"], init_pose=init))
-        ctx_b = api.Context(dev_index)       # its own stream, as a detector object has
-        ctx_b.upload_grid(1, wl["grid"])
-        qs = ctx_b.prepare_queries(qs)       # the csm_loop_query[] a C++ caller holds
-        ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0, as_records=True)
-        samples = []
-        for _ in range(9):
-            tb0 = time.perf_counter()
-            outs = ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0, as_records=True)
-            samples.append(time.perf_counter() - tb0)
-        tb = sorted(samples)[len(samples) // 2]      # median: host calls jitter
-        ctx_b.enable_kernel_timing(True)
-        ctx_b.reset_kernel_timing()
-        ctx_b.correlative_match_batch(qs, rx, ry, rt, L, 0.0, 0.0)
-        kms = {k: ctx_b.kernel_time(k)[0] for k in ("project", "bin", "score_coarse", "score_fine", "finalize")}
-        ctx_b.close()
-        batched = {"value": outs.total("candidates") / tb, "unit": "candidate poses/s",
-                   "queries_per_call": qs.n, "ms_per_call": tb * 1e3, "kernel_ms": kms,
-                   "note": "median of 9 calls; host-inclusive: scans in host memory, projection + "
-                           "search on device, summaries back on the host; one GPU"}
-
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # sanity: every scan found a pose and the record decodes
-    rec = np.frombuffer(results.cpu().numpy().tobytes(), dtype=np.int32).reshape(SCANS_PER_STEP, 12)
-    n_found = int(rec[:, 0].sum())
-
-    if rank == 0:
-        total = cands_per_step * args.steps * world
-        value = total / dt
-        windows_per_launch = SCANS_PER_STEP if batch_mode else 1
-        cands_per_launch = cands_per_step / SCANS_PER_STEP * windows_per_launch
-        alg_bytes = 2.0 * n_beams * cands_per_launch
-        avg_fine_s = (fine_ms / max(1, fine_n)) * 1e-3
-        achieved = alg_bytes / avg_fine_s / 1e9 if avg_fine_s > 0 else 0.0
-        out = {
-            "metric": "candidate poses scored/sec (CSM+BnB), 1/2/4/8 GPU; % HBM roofline",
-            "value": value,
-            "unit": "candidate poses/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",   # uint16 cells, exact u32/u64 integer sums; f64 replay of the winner
-            "data": "synthetic",
-            "config": {
-                "workload": "configs[1]: frontend CSM, 1080-beam scan, 400x400@5cm grid, "
-                            "+-2 m/+-30 deg window at 5 cm/0.5 deg, L=4",
-                "scans_per_step": SCANS_PER_STEP,
-                "mode": "batch: csm_score_windows_dev, one launch chain per step" if batch_mode
-                        else "streams: csm_score_window_dev per scan on %d stream(s)" % n_streams,
-                "streams": n_streams,
-                "candidates_per_scan": cands_per_step / SCANS_PER_STEP,
-                "beams": n_beams,
-                "parallelism": "scans sharded per GPU, all-gather of 48-B best records" if world > 1
-                               else "single GPU",
-                "poses_found": n_found,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_score_batch (fine level, %d windows per launch)" % SCANS_PER_STEP if batch_mode
-                          else "k_score (fine level)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(),
-                "avg_launch_us": avg_fine_s * 1e6,
-                "launches": fine_n,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "other_kernels_avg_us": {
-                    "score_coarse": coarse_ms / max(1, coarse_n) * 1e3,
-                    "bin": bin_ms / max(1, bin_n) * 1e3,
-                    "finalize": fin_ms / max(1, fin_n) * 1e3,
-                    "argmax": arg_ms / max(1, arg_n) * 1e3,
-                },
-            },
-        }
-        if batched is not None:
-            out["batched"] = batched
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
-        print(json.dumps(out), flush=True)
-
-    for c in ctxs:
-        c.close()
+    workload = args.workload
+    if workload == "auto":
+        workload = "csm" if world == 1 else "loop4"
+    stream = torch.cuda.Stream(dev)
+    if workload == "map":
+        run_map_workload(args, rank, world, dev, dev_index, rehearse)
+    elif workload in ("loop", "loop4"):
+        n_total = 2048 if workload == "loop4" else 256 * world
+        if rehearse and "CSM_BENCH_LOOP_TOTAL" in os.environ:
+            n_total = int(os.environ["CSM_BENCH_LOOP_TOTAL"])      # smaller rehearsal batches
+        run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_total, workload == "loop4")
+    else:
+        run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream)
     if world > 1:
         dist.destroy_process_group()
 

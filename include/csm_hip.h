@@ -11,13 +11,19 @@
  *    in _dev; inputs are borrowed for the duration of the call.
  *  - every function returns 0 on success or a negative errno-style code;
  *    csm_last_error() gives the text. Nothing throws across the boundary.
- *  - no global state: one csm_ctx per matcher / detector object, single caller
- *    per ctx (the reference never shares a matcher between its two threads,
+ *  - one csm_ctx per matcher / detector object, single caller per ctx (the
+ *    reference never shares a matcher between its two threads,
  *    src/slam_module_factory.cpp:102-104 vs src/loop_detector_factory.cpp:180-183).
+ *    All mutable state lives in the ctx. The one process-wide table is a
+ *    mutex-guarded record of the dynamic-LDS limit already granted to each
+ *    kernel function per device (a property of the function, not of a ctx).
  *  - occupancy values are the reference's raw uint16 cells: 0 = unknown,
  *    1..65535 <-> P in [0.001, 0.999] (inc/grid_map_new/grid_binary_bayes.hpp:163-176).
  *  - there is no CPU fallback: without a GPU every compute entry point fails
  *    with CSM_ENODEV.
+ *  - scans must hold finite ranges and angles ("no return" beams filtered out
+ *    upstream, as the reference's scan filters do): a non-finite value makes
+ *    the matching entry points fail with CSM_EINVAL.
  *  - limits: at most 12288 beams per scan; LowResolution / 2^NodeHeightMax up
  *    to 64 cells; grid + window up to ~2500 x 2500 cells per map (CSM_EINVAL
  *    beyond).
@@ -147,7 +153,9 @@ int  csm_create(const csm_config* cfg, csm_ctx** out);
 int  csm_destroy(csm_ctx* ctx);
 const char* csm_last_error(const csm_ctx* ctx);
 /* Use an existing HIP stream (hipStream_t) for all work of this ctx; NULL =
- * the ctx's own stream. */
+ * the ctx's own (non-blocking) stream, NOT the legacy default stream: a caller
+ * that wants its work ordered with the default stream passes hipStreamLegacy /
+ * hipStreamPerThread, or better a stream of its own. */
 int  csm_set_stream(csm_ctx* ctx, void* hip_stream);
 int  csm_synchronize(csm_ctx* ctx);
 
@@ -168,6 +176,14 @@ int  csm_build_pyramid(csm_ctx* ctx, uint64_t map_id, const int32_t* win_sizes,
                        int32_t n_levels);
 int  csm_download_level(csm_ctx* ctx, uint64_t map_id, int32_t level,
                         uint16_t* out /* rows*cols */);
+/* PrecomputeGridMaps for many finished local maps at once (what
+ * LoopDetectorBranchBound::Detect does lazily per query,
+ * src/mapping/loop_detector_branch_bound.cpp:83-89): makes sure every map of
+ * map_ids holds box-max(win_sizes[l]) for every l, building what is missing.
+ * Levels that exist are kept (unlike csm_build_pyramid, which rebuilds).
+ * Asynchronous on the ctx stream. */
+int  csm_build_pyramids(csm_ctx* ctx, const uint64_t* map_ids, int32_t n_maps,
+                        const int32_t* win_sizes, int32_t n_levels);
 
 /* ---- host-side set-up pieces (pure CPU, exported so the adapter and the
  * tests share one implementation) ---- */
@@ -192,6 +208,20 @@ int  csm_host_project(const csm_geometry* geom, const double sensor_pose[3],
                       const double* angles, const double* ranges, int32_t n,
                       int32_t* hit_col, int32_t* hit_row,
                       double* r_cos, double* r_sin);
+/* The same projection as the matchers run it: on the device, with a
+ * per-entry certificate. hit_col / hit_row [2*win_theta+1][n] (host) receive
+ * the device's indices; `uncertified` receives the flat indices t*n + i of the
+ * entries whose cell coordinate lies too close to a cell edge for the device's
+ * sin / cos to be trusted (at most uncertified_cap of them; *n_uncertified is
+ * the full count). Contract checked by the tests: every entry NOT listed
+ * equals csm_host_project's (glibc) index. The matchers recompute the listed
+ * ones on the host. Non-finite ranges or angles are rejected (CSM_EINVAL);
+ * the reference's upstream filters drop them before the matcher sees a scan. */
+int  csm_project_scan(csm_ctx* ctx, const csm_geometry* geom, const double sensor_pose[3],
+                      double step_theta, int32_t win_theta,
+                      const double* angles, const double* ranges, int32_t n,
+                      int32_t* hit_col, int32_t* hit_row, uint32_t* uncertified,
+                      int32_t uncertified_cap, int32_t* n_uncertified);
 /* value -> probability table, 65536 doubles
  * (inc/grid_map_new/grid_values.hpp:26-35) */
 void csm_host_probability_lut(double* lut);
@@ -274,6 +304,13 @@ int  csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
 int  csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
                                  int32_t n_queries, const csm_correlative_params* params,
                                  csm_summary* out);
+
+/* The raw records (csm_summary.raw) of the last csm_bnb_match_batch /
+ * csm_correlative_match_batch call on this ctx, in query order, copied device
+ * to device into dst_dev[n_queries] on the ctx stream (asynchronous): the
+ * send buffer of the multi-GPU all-gather without a host round trip
+ * (the concatenation of src/mapping/loop_detector_fpga_parallel.cpp:53-56). */
+int  csm_copy_last_batch_records(csm_ctx* ctx, csm_result* dst_dev);
 
 /* ScanMatcherGridSearch constructor arguments + thresholds
  * (inc/mapping/scan_matcher_grid_search.hpp, src/scan_matcher_factory.cpp) */

@@ -129,6 +129,8 @@ SIGNATURES = {
     "csm_release_grid": (C.c_int, [_ctx, C.c_uint64]),
     "csm_build_pyramid": (C.c_int, [_ctx, C.c_uint64, _P(C.c_int32), C.c_int32]),
     "csm_download_level": (C.c_int, [_ctx, C.c_uint64, C.c_int32, C.c_void_p]),
+    "csm_build_pyramids": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "csm_copy_last_batch_records": (C.c_int, [_ctx, C.c_void_p]),
     "csm_host_search_step": (C.c_int, [C.c_double, C.c_void_p, C.c_int32,
                                        _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "csm_host_window": (C.c_int, [C.c_double, C.c_double]),
@@ -140,6 +142,9 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "csm_host_probability_lut": (None, [C.c_void_p]),
+    "csm_project_scan": (C.c_int, [_ctx, _P(Geometry), C.c_void_p, C.c_double, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   _P(C.c_int32)]),
     "csm_score_window": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
                                    C.c_void_p, _P(Result)]),
     "csm_score_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,

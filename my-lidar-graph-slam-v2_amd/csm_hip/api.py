@@ -207,6 +207,32 @@ class Context:
         self._check(self.lib.csm_build_pyramid(
             self._ctx, map_id, w.ctypes.data_as(C.POINTER(C.c_int32)), w.size))
 
+    def project_scan(self, geom, sensor_pose, step_theta, win_theta, angles, ranges, cap=1 << 20):
+        """csm_project_scan: the device projection with its certificate. Returns
+        (col [nt, n], row [nt, n], flat indices of the uncertified entries, their full count)."""
+        a, r = _f64(angles), _f64(ranges)
+        n, nt = a.size, 2 * win_theta + 1
+        col = np.zeros((nt, n), np.int32)
+        row = np.zeros((nt, n), np.int32)
+        unc = np.zeros(cap, np.uint32)
+        count = C.c_int32(0)
+        g = L.Geometry(*geom)
+        sp = _f64(sensor_pose)
+        self._check(self.lib.csm_project_scan(self._ctx, C.byref(g), _ptr(sp), step_theta, win_theta,
+                                              _ptr(a), _ptr(r), n, _ptr(col), _ptr(row), _ptr(unc), cap,
+                                              C.byref(count)))
+        return col, row, unc[:min(count.value, cap)].copy(), count.value
+
+    def build_pyramids(self, map_ids, win_sizes):
+        """csm_build_pyramids: box-max(win) of every listed map for every win, built where missing."""
+        ids = np.ascontiguousarray(map_ids, dtype=np.uint64)
+        w = np.ascontiguousarray(win_sizes, dtype=np.int32)
+        self._check(self.lib.csm_build_pyramids(self._ctx, _ptr(ids), ids.size, _ptr(w), w.size))
+
+    def copy_last_batch_records(self, dst_ptr):
+        """Device-to-device copy of the last batch's records (query order) into dst_ptr."""
+        self._check(self.lib.csm_copy_last_batch_records(self._ctx, C.c_void_p(dst_ptr)))
+
     def download_level(self, map_id, level):
         out = np.zeros(self.shapes[map_id], np.uint16)
         self._check(self.lib.csm_download_level(self._ctx, map_id, level, _ptr(out)))

@@ -24,24 +24,25 @@ def shard_bounds(n_queries, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# csm_result as a numpy record: the same 48 bytes, no per-record Python loop
+RECORD_DTYPE = np.dtype([("found", "<i4"), ("best_x", "<i4"), ("best_y", "<i4"), ("best_theta", "<i4"),
+                         ("key", "<u8"), ("sum_values", "<u4"), ("known", "<u4"), ("tie_count", "<u4"),
+                         ("flags", "<u4"), ("score", "<f8")])
+assert RECORD_DTYPE.itemsize == RECORD_BYTES
+
+
 def records_to_bytes(raw_results):
     """list of dict (api.result_to_dict) -> uint8 [n, 48] in csm_result layout."""
-    arr = (L.Result * len(raw_results))()
-    for i, r in enumerate(raw_results):
-        a = arr[i]
-        a.found, a.best_x, a.best_y, a.best_theta = r["found"], r["best_x"], r["best_y"], r["best_theta"]
-        a.key, a.sum_values, a.known = r["key"], r["sum_values"], r["known"]
-        a.tie_count, a.flags, a.score = r["tie_count"], r["flags"], r["score"]
-    return np.frombuffer(bytes(arr), dtype=np.uint8).reshape(len(raw_results), RECORD_BYTES).copy()
+    arr = np.zeros(len(raw_results), RECORD_DTYPE)
+    for name in RECORD_DTYPE.names:
+        arr[name] = [r[name] for r in raw_results]
+    return arr.view(np.uint8).reshape(len(raw_results), RECORD_BYTES)
 
 
 def bytes_to_records(buf):
-    buf = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1, RECORD_BYTES)
-    arr = (L.Result * buf.shape[0]).from_buffer_copy(buf.tobytes())
-    return [dict(found=int(a.found), best_x=int(a.best_x), best_y=int(a.best_y),
-                 best_theta=int(a.best_theta), key=int(a.key), sum_values=int(a.sum_values),
-                 known=int(a.known), tie_count=int(a.tie_count), flags=int(a.flags),
-                 score=float(a.score)) for a in arr]
+    arr = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1, RECORD_BYTES).view(RECORD_DTYPE).reshape(-1)
+    cols = {name: arr[name].tolist() for name in RECORD_DTYPE.names}
+    return [dict(zip(cols, vals)) for vals in zip(*cols.values())]
 
 
 def allgather_records(local, n_queries, group=None, device=None):
@@ -74,9 +75,9 @@ class LoopDetectorBranchBoundHIP:
     (src/my_lidar_graph_slam/mapping/loop_detector_branch_bound.cpp:59-156),
     constructor arguments as in src/my_lidar_graph_slam/loop_detector_factory.cpp:161-183.
 
-    `scorer(queries) -> list of raw result dicts` defaults to the HIP batch; the
-    CPU (gloo) tests pass a stand-in so that the sharding and gather logic can
-    run without a GPU."""
+    `scorer(queries) -> uint8 [m, 48] records (or a list of raw result dicts)`
+    defaults to the HIP batch; the CPU (gloo) tests pass a stand-in so that the
+    sharding and gather logic can run without a GPU."""
 
     def __init__(self, name, ctx, range_x, range_y, range_theta, node_height_max,
                  score_threshold, known_rate_threshold, group=None, scorer=None, device=None):
@@ -92,8 +93,8 @@ class LoopDetectorBranchBoundHIP:
     def _hip_scorer(self, queries):
         rx, ry, rt, H = self.params
         outs = self.ctx.bnb_match_batch(queries, rx, ry, rt, H, self.score_threshold,
-                                        self.known_rate_threshold)
-        return [o["raw"] for o in outs]
+                                        self.known_rate_threshold, as_records=True)
+        return outs.record_bytes().reshape(-1, RECORD_BYTES)
 
     def detect(self, queries, grids=None):
         """queries: list of dict(map_id, geom, angles, ranges, rel_pose, init_pose);
@@ -111,7 +112,9 @@ class LoopDetectorBranchBoundHIP:
             for q in mine:
                 if not self.ctx.has_grid(q["map_id"]):
                     self.ctx.upload_grid(q["map_id"], grids[q["map_id"]])
-        local = records_to_bytes(self._scorer(mine)) if mine else np.zeros((0, RECORD_BYTES), np.uint8)
+        local = self._scorer(mine) if mine else np.zeros((0, RECORD_BYTES), np.uint8)
+        if not isinstance(local, np.ndarray):
+            local = records_to_bytes(local)
         if distributed and world > 1:
             allrec = allgather_records(local, n, self.group, self.device)
         else:

@@ -76,13 +76,19 @@ struct csm_ctx {
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
+    /* the final records of the last batch call in query order (csm_copy_last_batch_records) */
+    DevBuf rec_dev;
+    int rec_n = 0;
+    std::vector<csm_result> rec_patch;            /* host copies of records fixed up after the device pass */
     /* map building */
     DevBuf m_rays, m_recs, m_cell, m_lists, m_cnt, m_lut;
     double m_lut_hit = -1.0, m_lut_miss = -1.0;   /* probabilities the update tables were built for */
     bool m_apply_attr = false;
     hipEvent_t m_ev[2] = { nullptr, nullptr };    /* device_us of csm_map_build_info */
     std::vector<double> stage;                    /* host staging of one scan (angles, ranges) */
-    std::shared_ptr<void> resident_hold;          /* job tables of the last csm_score_windows_dev call */
+    /* job tables of csm_score_windows_dev calls (pageable sources of asynchronous
+     * uploads), each kept until the event recorded behind its launch chain has fired */
+    std::vector<std::pair<hipEvent_t, std::shared_ptr<void>>> resident_hold;
     /* the fine-level job of the last csm window, for the tie collection pass */
     csm::ScoreJob last_fine;
     unsigned flag_toggle = 0;     /* two flag words, used alternately: k_finalize of query i
@@ -184,6 +190,18 @@ double value_to_probability(unsigned v)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+/* A "no return" beam (inf / NaN range) has no hit point; the reference's scan
+ * filters drop such beams before a matcher sees the scan. The library refuses
+ * them instead of converting a non-finite coordinate to an int. */
+bool scan_is_finite(const csm_scan* scan)
+{
+    for (int i = 0; i < scan->n_points; ++i)
+        if (!std::isfinite(scan->ranges[i]) || !std::isfinite(scan->angles[i]))
+            return false;
+    return std::isfinite(scan->relative_sensor_pose[0]) && std::isfinite(scan->relative_sensor_pose[1]) &&
+           std::isfinite(scan->relative_sensor_pose[2]);
+}
+
 /* Do enough beams share cells for merging to pay? A merged entry costs a
  * multiply per gather (~3x the vector work of the plain path) and saves LDS
  * reads in proportion to the duplicates: break-even near 1.4 beams per cell
@@ -202,18 +220,19 @@ bool merging_pays(const double* angles, const double* ranges, int n, double res)
     return n >= 1.4 * cells;
 }
 
-/* k_bin's LDS: 6 per-tile arrays, 2 * kBlock scan words, hash keys + values */
+/* k_bin's LDS: 8 per-tile arrays, 2 * kBinBlock scan words, hash keys + values
+ * (load factor <= 2/3 when every beam lands on a cell of its own) */
 int bin_hash_size(int n_points)
 {
     int h = 1024;
-    while (h < 2 * n_points && h < 16384)
+    while (2 * h < 3 * n_points && h < 32768)
         h <<= 1;
     return h;
 }
 
 size_t bin_lds_bytes(int tiles, int n_points)
 {
-    return ((size_t)6 * tiles + 2 * kBlock + 2 * (size_t)bin_hash_size(n_points)) * 4;
+    return ((size_t)8 * tiles + 2 * kBinBlock + 2 * (size_t)bin_hash_size(n_points)) * 4;
 }
 
 
@@ -227,6 +246,7 @@ struct PassPlan {
     int nx = 0, ny = 0, stride = 1, log2s = 0;
     int cbx = 0, groups = 0, R = 0, ncbx = 0, ncby = 0, lstride = 0;
     bool weighted = true;     /* entries carry beam multiplicities */
+    bool pairs = false;       /* pair-row fine kernel (k_score_pairs): lstride = slots per pair row */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -308,6 +328,59 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
     return true;
 }
 
+/* The pair-row fine kernel (k_score_pairs<LS, 8, W>): instantiated for these
+ * (candidate-block width, slots per pair row). A half-wave that straddles two
+ * lane groups reads conflict-free iff (R/2) * LS == cbx (mod 32); LS >= cbx + 65
+ * holds the widest staged row (alignment column + 64-cell tile + cbx - 1). */
+struct PairShape { int cbx, ls; };
+const PairShape kPairShapes[] = { { 20, 93 }, { 32, 104 }, { 52, 125 }, { 64, 136 },
+                                  { 84, 157 }, { 96, 168 }, { 116, 189 } };
+const int kPairR = 8;
+
+size_t pair_lds_bytes(int ls, int cby)
+{
+    return ((size_t)((kTile + cby) / 2 + 1) * 2 * ls + kPbMax) * 4;
+}
+
+bool plan_pass_pairs(int nx, int ny, PassPlan* out)
+{
+    if (const char* e = getenv("CSM_FINE_PAIRS"))       /* tuning / fallback knob */
+        if (atoi(e) == 0)
+            return false;
+    const int R = kPairR;
+    double best = -1.0;
+    for (const PairShape& sh : kPairShapes) {
+        PassPlan p;
+        p.nx = nx;
+        p.ny = ny;
+        p.stride = 1;
+        p.log2s = 0;
+        p.pairs = true;
+        p.R = R;
+        p.cbx = sh.cbx;
+        p.lstride = sh.ls;
+        p.ncbx = ceil_div(nx, sh.cbx);
+        int g = std::min(std::min(kBlock / sh.cbx, ceil_div(ny, R)), kPairMaxCby / R);
+        /* two workgroups per CU: at most 80 KB of LDS each */
+        while (g > 1 && pair_lds_bytes(sh.ls, g * R) > 80 * 1024)
+            --g;
+        if (pair_lds_bytes(sh.ls, g * R) > 160 * 1024 - 256)
+            continue;
+        p.ncby = ceil_div(ny, g * R);
+        g = ceil_div(ceil_div(ny, p.ncby), R);          /* balance the row blocks */
+        p.groups = g;
+        /* per (block, tile): staging grows with the region, the gather does not
+         * depend on how many lanes are useful */
+        const double cost = (double)p.ncbx * p.ncby *
+                            (0.04 * ((kTile + g * R) / 2 + 1) * sh.ls + 1260.0);
+        if (best < 0 || cost < best) {
+            best = cost;
+            *out = p;
+        }
+    }
+    return best >= 0;
+}
+
 /* Two LDS buffers (one barrier per tile, staging overlapped with the gather)
  * when they fit; CSM_NBUF overrides for tuning. */
 int pick_buffers(size_t lds_one, long blocks)
@@ -323,6 +396,8 @@ int pick_buffers(size_t lds_one, long blocks)
 
 size_t pass_lds_bytes(const PassPlan& p)
 {
+    if (p.pairs)
+        return pair_lds_bytes(p.lstride, p.groups * p.R);
     const int cby = p.groups * p.R;
     const int rows = p.stride > 1 ? ((kTile + p.stride - 1) / p.stride + cby - 1) * p.stride
                                   : kTile + cby - 1;
@@ -357,7 +432,7 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     p->y_lo = -w->win_y;
     p->x_hi = p->x_lo + p->nx - 1;
     p->y_hi = p->y_lo + p->ny - 1;
-    if (!plan_pass(p->nx, p->ny, 1, &p->fine))
+    if (!plan_pass_pairs(p->nx, p->ny, &p->fine) && !plan_pass(p->nx, p->ny, 1, &p->fine))
         return fail(ctx, CSM_EINVAL, "internal: no launch geometry for the fine level");
     p->fine.weighted = w->merge_mode == 0;
     if (p->L > 1 && !plan_pass(p->nxc, p->nyc, p->L, &p->coarse))
@@ -443,9 +518,52 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
                            ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices, n_buf); \
     } while (0)
 
+#define PAIR_CASE(LS, CALL)                                                            \
+    if (pp.lstride == LS && pp.R == 8) {                                               \
+        if (pp.weighted) {                                                             \
+            CALL(LS, 8, true);                                                         \
+        } else {                                                                       \
+            CALL(LS, 8, false);                                                        \
+        }                                                                              \
+        launched = true;                                                               \
+    }
+#define PAIR_DISPATCH(CALL)                                                            \
+    do {                                                                               \
+        PAIR_CASE(93, CALL) PAIR_CASE(104, CALL) PAIR_CASE(125, CALL)                  \
+        PAIR_CASE(136, CALL) PAIR_CASE(157, CALL) PAIR_CASE(168, CALL)                 \
+        PAIR_CASE(189, CALL)                                                           \
+    } while (0)
+
+#define CALL_PAIRS_SINGLE(LS, RR, WW)                                                  \
+    do {                                                                               \
+        int rc_ = set_lds(ctx, k_score_pairs<LS, RR, WW>, lds);                        \
+        if (rc_)                                                                       \
+            return rc_;                                                                \
+        hipLaunchKernelGGL((k_score_pairs<LS, RR, WW>), grid, dim3(kBlock), lds, ctx->stream, \
+                           job, pp.cbx, pp.groups);                                    \
+    } while (0)
+
+#define CALL_PAIRS_BATCH(LS, RR, WW)                                                   \
+    do {                                                                               \
+        int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);                  \
+        if (rc_)                                                                       \
+            return rc_;                                                                \
+        hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
+                           ctx->stream, jobs_dev, pp.cbx, pp.groups);                  \
+    } while (0)
+
 int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta, int n_slices)
 {
     const dim3 grid(pp.ncb(), n_theta, n_slices);
+    if (pp.pairs) {
+        const size_t lds = pass_lds_bytes(pp);
+        bool launched = false;
+        PAIR_DISPATCH(CALL_PAIRS_SINGLE);
+        if (!launched)
+            return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
+        HIP_TRY(ctx, hipGetLastError());
+        return CSM_OK;
+    }
     const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
     size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
@@ -467,8 +585,13 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
         launched = true;                                                               \
     }
 
-int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta)
+int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n_theta)
 {
+    /* only the lane <-> candidate mapping (cbx, groups, R) matters to this pass:
+     * a pair plan borrows the R = 8 instantiation of the plain kernel */
+    PassPlan pp = plan;
+    if (pp.pairs)
+        pp.lstride = 128;
     const dim3 grid(pp.ncb(), n_theta, 1);
     bool launched = false;
     ARGMAX_CASE(96, 4) ARGMAX_CASE(96, 5) ARGMAX_CASE(96, 6) ARGMAX_CASE(96, 7) ARGMAX_CASE(96, 8)
@@ -485,6 +608,17 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
                        int n_theta_max, int n_slices)
 {
     const dim3 grid(pp.ncb(), n_theta_max, n_jobs * n_slices);
+    if (pp.pairs) {
+        if (n_slices != 1)
+            return fail(ctx, CSM_EINVAL, "internal: pair kernel batches are not tile-split");
+        const size_t lds = pass_lds_bytes(pp);
+        bool launched = false;
+        PAIR_DISPATCH(CALL_PAIRS_BATCH);
+        if (!launched)
+            return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
+        HIP_TRY(ctx, hipGetLastError());
+        return CSM_OK;
+    }
     const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
     size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
@@ -674,22 +808,34 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.hash_size = bin_hash_size(p.n);
     bj.max_mult = p.fine.weighted ? kMaxMult : 1;
     bj.lstride = p.fine.lstride;
+    bj.pair_mode = p.fine.pairs ? 1 : 0;
     bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
+    const bool coarse_exits = w->min_known <= 1 && !force_coarse;   /* unless a beam reaches the band */
     if (p.L > 1) {
         bj.n_band = 1;
         bj.band_win[0] = p.L;
         bj.band_nx[0] = p.nxc;
         bj.band_ny[0] = p.nyc;
-        /* the coarse pass accumulates with atomics: cleared here, per slice */
-        bj.zero_a = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
-        bj.zero_b = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
-        bj.zero_words = p.nxc * p.nyc;
     }
     {
         const size_t lds = bin_lds_bytes(p.tiles_x * p.tiles_y, p.n);
         if ((rc = set_lds(ctx, k_bin, lds))) return rc;
         ScopedTimer tm(ctx, "bin");
-        hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBlock), lds, ctx->stream, bj);
+        hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBinBlock), lds, ctx->stream, bj);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (p.L > 1) {
+        /* the coarse pass accumulates with atomics: its sums are cleared first, but
+         * only when it is going to run (k_zero_if_band reads the band flag k_bin set) */
+        ZeroJob zj;
+        zj.a = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
+        zj.b = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
+        zj.words = nt * p.nxc * p.nyc;
+        zj.flags = flags;
+        zj.always = coarse_exits ? 0 : 1;
+        zj.pad = 0;
+        const int zb = (int)std::min<size_t>(256, (zj.words + 255) / 256);
+        hipLaunchKernelGGL(k_zero_if_band, dim3(std::max(1, zb), 1), dim3(256), 0, ctx->stream, zj);
         HIP_TRY(ctx, hipGetLastError());
     }
 
@@ -720,7 +866,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         cj.acc_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
         cj.acc_k = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
         cj.rank_l = 1;
-        cj.skip_unless_band = w->min_known <= 1 && !force_coarse;
+        cj.skip_unless_band = coarse_exits;
         const size_t nodes = nt * p.nxc * p.nyc;
         (void)nodes;
         ScopedTimer tm(ctx, "score_coarse");
@@ -749,7 +895,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         fj.elig[0].div = p.L;
         fj.elig[0].nxc = p.nxc;
         fj.elig[0].nyc = p.nyc;
-        fj.elig_only_if_band = w->min_known <= 1 && !force_coarse;
+        fj.elig_only_if_band = coarse_exits;
     } else {
         fj.check_own_known = 1;
     }
@@ -1013,7 +1159,7 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
-                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc,
+                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
     for (DevBuf* b : bufs)
         if (b->p)
@@ -1025,6 +1171,8 @@ int csm_destroy(csm_ctx* ctx)
             (void)hipEventDestroy(s.a);
             (void)hipEventDestroy(s.b);
         }
+    for (auto& h : ctx->resident_hold)
+        (void)hipEventDestroy(h.first);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->m_ev)
@@ -1371,6 +1519,8 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     if (!ctx || !geom || !scan || !initial_pose || !prm || !out || scan->n_points < 1 ||
         prm->low_resolution < 1)
         return fail(ctx, CSM_EINVAL, "csm_correlative_match: bad arguments");
+    if (!scan->angles || !scan->ranges || !scan_is_finite(scan))
+        return fail(ctx, CSM_EINVAL, "csm_correlative_match: scan holds a non-finite range or angle");
     DeviceGrid* g = find_grid(ctx, map_id);
     if (!g)
         return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
@@ -1665,6 +1815,21 @@ int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BatchPrep& p, const
     return CSM_OK;
 }
 
+/* The device copy of a batch's final records: sized here, filled by
+ * run_batch_group, handed out by csm_copy_last_batch_records. */
+int begin_batch_records(csm_ctx* ctx, int n_queries)
+{
+    ctx->rec_n = 0;
+    int rc = ensure(ctx, ctx->rec_dev, (size_t)n_queries * sizeof(csm_result));
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   /* patches of the previous call have landed */
+    ctx->rec_patch.clear();
+    ctx->rec_patch.reserve((size_t)n_queries);         /* no reallocation under a pending copy */
+    ctx->rec_n = n_queries;
+    return CSM_OK;
+}
+
 /* What distinguishes the two batched searches. */
 struct BatchSpec {
     bool bnb = true;          /* branch and bound (leaf + 2^h levels) or correlative (fine + one
@@ -1769,10 +1934,13 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
 
     /* ---- launch geometry shared by the group ---- */
     std::vector<PassPlan> lp(H + 1);
-    for (int h = 0; h <= H; ++h)
+    for (int h = 0; h <= H; ++h) {
+        if (h == 0 && plan_pass_pairs(nx, ny, &lp[0]))
+            continue;
         if (!plan_pass(nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
             return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
                         spec.stride[h]);
+    }
     if (resident) {
         lp[0].weighted = resident->windows[idx[0]].merge_mode == 0;
     } else {
@@ -1804,7 +1972,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     if ((rc = ensure(ctx, ctx->b_best, best_total * sizeof(BlockBest)))) return rc;
     if ((rc = ensure(ctx, ctx->b_out, (size_t)nq * (sizeof(csm_result) + 4)))) return rc;
     const size_t jobs_bytes = (size_t)nq * (sizeof(ProjJob) + sizeof(BinJob) + sizeof(FinalJob) +
-                                            (size_t)(H + 1) * sizeof(ScoreJob));
+                                            (size_t)(H + 1) * sizeof(ScoreJob) + (size_t)H * sizeof(ZeroJob));
     if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + 1024))) return rc;
 
     double* d_scans = reinterpret_cast<double*>(ctx->b_prod.p);
@@ -1823,14 +1991,14 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     if (!resident)
         HIP_TRY(ctx, hipMemcpyAsync(d_scans, scans.data(), scan_total * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, (size_t)nq * 4, ctx->stream));
-    if (lvl_total)
-        HIP_TRY(ctx, hipMemsetAsync(d_lvl_s, 0, lvl_total * 8, ctx->stream));
 
     /* ---- job tables ---- */
     std::vector<ProjJob> ij(nq);
     std::vector<BinJob> bj(nq);
     std::vector<FinalJob> fj(nq);
     std::vector<std::vector<ScoreJob>> sj(H + 1, std::vector<ScoreJob>(nq));
+    std::vector<ZeroJob> zj((size_t)nq * H);
+    size_t zero_words_max = 0;
     for (int k = 0; k < nq; ++k) {
         const csm_loop_query& q = queries[idx[k]];
         const csm_summary& o = out[idx[k]];
@@ -1891,6 +2059,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.hash_size = bin_hash_size(p.n);
         B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
+        B.pair_mode = lp[0].pairs ? 1 : 0;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {
             B.band_win[h - 1] = spec.stride[h];
@@ -1929,6 +2098,15 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
             S.sorted_pb = B.sorted_rc;
             S.acc_s = d_lvl_s + p.lvl_off[h];
             S.acc_k = d_lvl_k + p.lvl_off[h];
+            /* the level's atomic accumulators: cleared only when the pass will run */
+            ZeroJob& Z0 = zj[(size_t)k * H + (h - 1)];
+            Z0.a = S.acc_s;
+            Z0.b = S.acc_k;
+            Z0.words = (size_t)p.n_theta * S.nx * S.ny;
+            Z0.flags = d_flags + k;
+            Z0.always = S.skip_unless_band ? 0 : 1;
+            Z0.pad = 0;
+            zero_words_max = std::max(zero_words_max, Z0.words);
         }
         ScoreJob& F = sj[0][k];
         F = base;
@@ -1984,9 +2162,13 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         return hipMemcpyAsync(*dev, src, bytes, hipMemcpyHostToDevice, ctx->stream);
     };
     /* sections were sized without the 256-byte rounding: grow if needed */
-    if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + 256 * (size_t)(H + 8)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + (size_t)nq * 4 + 256 * (size_t)(H + 10)))) return rc;
     jb = reinterpret_cast<char*>(ctx->b_jobs.p);
-    char *d_ij, *d_bj, *d_fj;
+    char *d_ij, *d_bj, *d_fj, *d_idx = nullptr, *d_zj = nullptr;
+    if (H > 0)
+        HIP_TRY(ctx, put(zj.data(), zj.size() * sizeof(ZeroJob), &d_zj));
+    if (!resident)
+        HIP_TRY(ctx, put(idx.data(), (size_t)nq * sizeof(int), &d_idx));
     std::vector<char*> d_sj(H + 1);
     HIP_TRY(ctx, put(ij.data(), nq * sizeof(ProjJob), &d_ij));
     HIP_TRY(ctx, put(bj.data(), nq * sizeof(BinJob), &d_bj));
@@ -2004,8 +2186,14 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     {
         if ((rc = set_lds(ctx, k_bin_batch, bin_lds))) return rc;
         ScopedTimer tm(ctx, "bin");
-        hipLaunchKernelGGL(k_bin_batch, dim3(n_theta_max, nq), dim3(kBlock), bin_lds, ctx->stream,
+        hipLaunchKernelGGL(k_bin_batch, dim3(n_theta_max, nq), dim3(kBinBlock), bin_lds, ctx->stream,
                            reinterpret_cast<const BinJob*>(d_bj));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (H > 0) {
+        const int zb = (int)std::min<size_t>(64, (zero_words_max + 255) / 256);
+        hipLaunchKernelGGL(k_zero_if_band_batch, dim3(std::max(1, zb), nq * H), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const ZeroJob*>(d_zj));
         HIP_TRY(ctx, hipGetLastError());
     }
     for (int h = H; h >= 1; --h) {
@@ -2037,11 +2225,26 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         /* asynchronous: the records stay on the device. The job tables were handed
          * to hipMemcpyAsync from pageable memory; keep them alive until the next
          * call instead of relying on the copy having staged them already. */
-        ctx->resident_hold = std::make_shared<
+        hipEvent_t done = nullptr;
+        if (!ctx->event_pool.empty()) {
+            done = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            HIP_TRY(ctx, hipEventCreate(&done));
+        }
+        HIP_TRY(ctx, hipEventRecord(done, ctx->stream));
+        ctx->resident_hold.emplace_back(done, std::make_shared<
             std::tuple<std::vector<ProjJob>, std::vector<BinJob>, std::vector<FinalJob>,
-                       std::vector<std::vector<ScoreJob>>>>(std::move(ij), std::move(bj), std::move(fj),
-                                                            std::move(sj));
+                       std::vector<std::vector<ScoreJob>>, std::vector<ZeroJob>>>(
+            std::move(ij), std::move(bj), std::move(fj), std::move(sj), std::move(zj)));
         return CSM_OK;
+    }
+    /* device copy of the records in query order (csm_copy_last_batch_records) */
+    csm_result* rec_dev = reinterpret_cast<csm_result*>(ctx->rec_dev.p);
+    if (rec_dev) {
+        hipLaunchKernelGGL(k_scatter_records, dim3(ceil_div(nq, 256)), dim3(256), 0, ctx->stream, d_out,
+                           reinterpret_cast<const int32_t*>(d_idx), rec_dev, nq);
+        HIP_TRY(ctx, hipGetLastError());
     }
     std::vector<csm_result> res(nq);
     HIP_TRY(ctx, hipMemcpyAsync(res.data(), d_out, (size_t)nq * sizeof(csm_result),
@@ -2065,6 +2268,12 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
                     return rc;
                 res[k] = one.raw;
                 res[k].flags |= why & CSM_FLAG_PROJ_DELTA;
+            }
+            if (rec_dev) {
+                /* fixed up on the host: patch the device copy (the source stays alive in the ctx) */
+                ctx->rec_patch.push_back(res[k]);
+                HIP_TRY(ctx, hipMemcpyAsync(rec_dev + idx[k], &ctx->rec_patch.back(), sizeof(csm_result),
+                                            hipMemcpyHostToDevice, ctx->stream));
             }
         }
         o.raw = res[k];
@@ -2091,6 +2300,11 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
         return fail(ctx, CSM_EINVAL, "csm_bnb_match_batch: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int H = prm->node_height_max;
+    {
+        int rc = begin_batch_records(ctx, n_queries);
+        if (rc)
+            return rc;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     /* pyramids: build and cache per map id, as mPrecompMaps does
      * (loop_detector_branch_bound.cpp:83-89) */
@@ -2098,6 +2312,8 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
     for (int i = 0; i < n_queries; ++i) {
         if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
             return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
+        if (!scan_is_finite(&queries[i].scan))
+            return fail(ctx, CSM_EINVAL, "query %d: scan holds a non-finite range or angle", i);
         DeviceGrid* g = find_grid(ctx, queries[i].map_id);
         if (!g)
             return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
@@ -2161,11 +2377,18 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int L = prm->low_resolution;
     const int H = L > 1 ? 1 : 0;
+    {
+        int rc = begin_batch_records(ctx, n_queries);
+        if (rc)
+            return rc;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
     for (int i = 0; i < n_queries; ++i) {
         if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
             return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
+        if (!scan_is_finite(&queries[i].scan))
+            return fail(ctx, CSM_EINVAL, "query %d: scan holds a non-finite range or angle", i);
         DeviceGrid* g = find_grid(ctx, queries[i].map_id);
         if (!g)
             return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
@@ -2223,6 +2446,8 @@ int csm_grid_search_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     if (!ctx || !geom || !scan || !initial_pose || !prm || !out || scan->n_points < 1 ||
         !(prm->step_x > 0.0) || !(prm->step_y > 0.0) || !(prm->step_theta > 0.0))
         return fail(ctx, CSM_EINVAL, "csm_grid_search_match: bad arguments");
+    if (!scan->angles || !scan->ranges || !scan_is_finite(scan))
+        return fail(ctx, CSM_EINVAL, "csm_grid_search_match: scan holds a non-finite range or angle");
     DeviceGrid* g = find_grid(ctx, map_id);
     if (!g)
         return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_id);
@@ -2371,6 +2596,17 @@ int csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, cons
         groups[{ nx, ny, L, w.merge_mode }].push_back(i);
     }
     ResidentBatch resident { windows, hit_col_dev, hit_row_dev, out_dev };
+    /* drop the tables of earlier calls whose launch chains have completed */
+    while (!ctx->resident_hold.empty()) {
+        const bool full = ctx->resident_hold.size() >= 256;
+        hipEvent_t ev = ctx->resident_hold.front().first;
+        if (full)
+            HIP_TRY(ctx, hipEventSynchronize(ev));
+        else if (hipEventQuery(ev) != hipSuccess)
+            break;
+        ctx->event_pool.push_back(ev);
+        ctx->resident_hold.erase(ctx->resident_hold.begin());
+    }
     for (auto& kv : groups) {
         const int L = kv.first[2];
         BatchSpec spec;
@@ -2382,6 +2618,99 @@ int csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, cons
         int rc = run_batch_group(ctx, queries.data(), kv.second, levels, spec, nullptr, &resident);
         if (rc)
             return rc;
+    }
+    return CSM_OK;
+}
+
+/* The device projection (k_project) on its own, for parity tests of A3 */
+int csm_project_scan(csm_ctx* ctx, const csm_geometry* geom, const double sensor_pose[3],
+                     double step_theta, int32_t win_theta, const double* angles, const double* ranges,
+                     int32_t n, int32_t* hit_col, int32_t* hit_row, uint32_t* uncertified,
+                     int32_t uncertified_cap, int32_t* n_uncertified)
+{
+    if (!ctx || !geom || !sensor_pose || !angles || !ranges || n < 1 || win_theta < 0 || !hit_col ||
+        !hit_row || !n_uncertified || uncertified_cap < 0 || (uncertified_cap > 0 && !uncertified))
+        return fail(ctx, CSM_EINVAL, "csm_project_scan: bad arguments");
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(ranges[i]) || !std::isfinite(angles[i]))
+            return fail(ctx, CSM_EINVAL, "csm_project_scan: beam %d is not finite", i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n_theta = 2 * win_theta + 1;
+    const size_t hn = (size_t)n_theta * n;
+    int rc;
+    if ((rc = ensure(ctx, ctx->hits, hn * 8 + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->scan_dev, (size_t)n * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->unc, 16 + (size_t)std::max(uncertified_cap, 1) * 4))) return rc;
+    int32_t* col_dev = reinterpret_cast<int32_t*>(ctx->hits.p);
+    int32_t* row_dev = col_dev + hn;
+    double* ang_dev = reinterpret_cast<double*>(ctx->scan_dev.p);
+    double* rng_dev = ang_dev + n;
+    uint32_t* unc_count = reinterpret_cast<uint32_t*>(ctx->unc.p);
+    uint32_t* unc_list = unc_count + 4;
+    HIP_TRY(ctx, hipMemcpyAsync(ang_dev, angles, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(rng_dev, ranges, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(unc_count, 0, 16, ctx->stream));
+    ProjJob pj;
+    std::memset(&pj, 0, sizeof(pj));
+    pj.angles = ang_dev;
+    pj.ranges = rng_dev;
+    pj.hit_col = col_dev;
+    pj.hit_row = row_dev;
+    pj.unc_count = unc_count;
+    pj.unc_list = unc_list;
+    pj.unc_cap = (uint32_t)uncertified_cap;
+    pj.n_theta = n_theta;
+    pj.n_points = n;
+    pj.win_theta = win_theta;
+    pj.sensor_x = sensor_pose[0];
+    pj.sensor_y = sensor_pose[1];
+    pj.sensor_theta = sensor_pose[2];
+    pj.step_theta = step_theta;
+    pj.off_x = geom->offset_x;
+    pj.off_y = geom->offset_y;
+    pj.res = geom->resolution;
+    hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), n_theta), dim3(kBlock), 0, ctx->stream, pj);
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t count = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(hit_col, col_dev, hn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hit_row, row_dev, hn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&count, unc_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_uncertified = (int32_t)count;
+    const uint32_t have = std::min<uint32_t>(count, (uint32_t)uncertified_cap);
+    if (have)
+        HIP_TRY(ctx, hipMemcpy(uncertified, unc_list, (size_t)have * 4, hipMemcpyDeviceToHost));
+    return CSM_OK;
+}
+
+int csm_copy_last_batch_records(csm_ctx* ctx, csm_result* dst_dev)
+{
+    if (!ctx || !dst_dev)
+        return fail(ctx, CSM_EINVAL, "csm_copy_last_batch_records: bad arguments");
+    if (ctx->rec_n < 1 || !ctx->rec_dev.p)
+        return fail(ctx, CSM_ENOENT, "no batch has been scored on this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_dev, ctx->rec_dev.p, (size_t)ctx->rec_n * sizeof(csm_result),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    return CSM_OK;
+}
+
+int csm_build_pyramids(csm_ctx* ctx, const uint64_t* map_ids, int32_t n_maps, const int32_t* win_sizes,
+                       int32_t n_levels)
+{
+    if (!ctx || !map_ids || n_maps < 1 || !win_sizes || n_levels < 1)
+        return fail(ctx, CSM_EINVAL, "csm_build_pyramids: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_maps; ++i) {
+        DeviceGrid* g = find_grid(ctx, map_ids[i]);
+        if (!g)
+            return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_ids[i]);
+        for (int l = 0; l < n_levels; ++l) {
+            int index = 0;
+            int rc = level_for_window(ctx, *g, win_sizes[l], &index);
+            if (rc)
+                return rc;
+        }
     }
     return CSM_OK;
 }

@@ -10,10 +10,12 @@ namespace csm {
 constexpr int kTile = 64;        /* endpoint tile edge, cells */
 constexpr int kMaxRegionRows = 128;        /* LDS region rows of a stride-1 job */
 constexpr int kMaxRegionRowsStrided = 128; /* ... of a strided (coarser level) job */
+constexpr int kPairMaxCby = 56;  /* candidate rows per workgroup of the pair-row fine kernel */
 constexpr int kPbMax = 1024;       /* entries per TileRec: k_bin splits fuller tiles */
 constexpr int kMaxMult = 15;       /* beams merged into one (cell, multiplicity) entry */
 constexpr int kMaxPoints = 12288;  /* beams per scan (hash table of k_bin: 16384 slots) */
 constexpr int kBlock = 512;      /* threads per workgroup (8 wave64) */
+constexpr int kBinBlock = 256;   /* threads per workgroup of the binning kernel */
 constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
 /* internal flag bit (never returned): some beam can reach the negative edge
  * band of a coarser level for some candidate offset */
@@ -26,7 +28,8 @@ struct TileRec {
     uint32_t start;      /* first beam in the slice's sorted list */
     uint32_t count;
     int32_t  h, w;       /* bounding box extent, cells (<= kTile) */
-    int32_t  pad[2];
+    int32_t  pad[2];     /* entries of class "both rows" / "even row only" in this record
+                            (the rest: "odd row only"); single mode: 0, count */
 };
 
 /* Best candidate of one workgroup (or of a reduction of several). */
@@ -66,6 +69,7 @@ struct BinJob {
     int32_t hash_size;         /* power of two >= 4/3 n_points (LDS hash table of k_bin) */
     int32_t max_mult;          /* kMaxMult: merge same-cell beams; 1: one entry per beam */
     int32_t lstride;
+    int32_t pair_mode;         /* entries are aligned row pairs (pair-row fine kernel) */
     /* first row / column of the map that holds a known cell: a box that ends
      * before it is unknown on every level, so reading it as unknown is right */
     int32_t known_r0, known_c0;
@@ -73,6 +77,16 @@ struct BinJob {
     int32_t n_band;
     int32_t band_win[kMaxElig];
     int32_t band_nx[kMaxElig], band_ny[kMaxElig];
+};
+
+/* k_zero_if_band: clear a[0..words) (and b) when the query's band flag is set */
+struct ZeroJob {
+    uint32_t* a;
+    uint32_t* b;
+    size_t words;
+    const uint32_t* flags;
+    int32_t always;
+    int32_t pad;
 };
 
 /* Score every candidate of one level of one query. */

@@ -1,8 +1,9 @@
 /* csm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the
  * correlative scan-matching hot path.
  *
- * K0 k_bin       bins the beams of one theta slice by 32x32-cell endpoint tile
- *                (LDS counting sort), emits packed LDS offsets per beam.
+ * K0 k_bin       merges the beams of one theta slice into (cell, multiplicity)
+ *                entries (LDS hash table), sorts them by 64x64-cell endpoint
+ *                tile, emits packed LDS offsets per entry.
  * K1 k_score     one workgroup = (theta slice, block of candidate offsets):
  *                for every non-empty endpoint tile it stages tile + window halo
  *                of the uint16 grid into LDS with 16-byte coalesced loads, then
@@ -26,6 +27,8 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "csm_device.hpp"
 #include "../../include/csm_hip.h"
@@ -70,19 +73,39 @@ __device__ __forceinline__ int cell_index(double pos, double off, double res)
 }
 
 /* ------------------------------------------------------------------ K0 */
+/* One workgroup (kBinBlock threads) per theta slice.
+ *
+ * Entries. Beams that land on the same cell of this slice add the same value to
+ * every candidate, so they are merged through an LDS hash table into (cell,
+ * multiplicity <= kMaxMult) entries. In pair mode (the pair-row fine kernel)
+ * the unit is an ALIGNED ROW PAIR of one column -- rows (2k, 2k + 1) of the
+ * tile frame -- with one multiplicity per row (m_even, m_odd): the fine kernel
+ * reads both rows with one ds_read_b64, so a vertical run of hit cells costs
+ * about half the LDS reads. Entries of a tile are sorted by class (both rows
+ * hit / even row only / odd row only) so that the gather loops have no
+ * per-entry branch; TileRec.pad[0..1] hold the first two class counts.
+ *
+ * Entry words:
+ *   sorted_pb, single mode: mult << 16 | (row * lstride + col)
+ *   sorted_pb, pair mode:   m_odd << 20 | m_even << 16 | (pair_row * 2 * lstride + 2 * col)
+ *   sorted_rc (strided levels): m_odd << 28 | m_even << 24 | row << 16 | col
+ * rows / cols relative to the tile's bounding box (TileRec.r0 / c0); in pair
+ * mode r0 is rounded down to an even row of the tile frame. */
 __device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
     extern __shared__ uint32_t sm_bin[];
     const int ntile = job.tiles_x * job.tiles_y;
-    uint32_t* hist = sm_bin;            /* [ntile] entry counts, later cursors */
+    uint32_t* hist = sm_bin;            /* [ntile] entry counts, later the "both" cursor */
     uint32_t* first = sm_bin + ntile;   /* [ntile] start offsets */
     uint32_t* bb_rmin = first + ntile;  /* [ntile] beam bounding box inside the tile */
     uint32_t* bb_rmax = bb_rmin + ntile;
     uint32_t* bb_cmin = bb_rmax + ntile;
     uint32_t* bb_cmax = bb_cmin + ntile;
-    uint32_t* part = bb_cmax + ntile;   /* [2 * kBlock] */
-    uint32_t* hkey = part + 2 * kBlock; /* [hash_size] (tile, cell) + 1, 0 = empty */
-    uint32_t* hval = hkey + job.hash_size;   /* [hash_size] beams on that cell */
+    uint32_t* n_both = bb_cmax + ntile; /* [ntile] class counts, later cursors */
+    uint32_t* n_even = n_both + ntile;
+    uint32_t* part = n_even + ntile;    /* [2 * kBinBlock] */
+    uint32_t* hkey = part + 2 * kBinBlock;   /* [hash_size] (tile, cell) + 1, 0 = empty */
+    uint32_t* hval = hkey + job.hash_size;   /* [hash_size] beams on that cell: even row | odd row << 16 */
     const int t = blockIdx.x;
     if (t >= job.n_theta)
         return;
@@ -91,32 +114,34 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int32_t* col = job.hit_col + (size_t)t * n;
     const int32_t* row = job.hit_row + (size_t)t * n;
     const uint32_t hmask = (uint32_t)job.hash_size - 1u;
+    const bool pairs = job.pair_mode != 0;
 
     if (job.zero_a)
-        for (int i = tid; i < job.zero_words; i += kBlock) {
+        for (int i = tid; i < job.zero_words; i += kBinBlock) {
             job.zero_a[(size_t)t * job.zero_words + i] = 0;
             job.zero_b[(size_t)t * job.zero_words + i] = 0;
         }
-    for (int i = tid; i < ntile; i += kBlock) {
+    for (int i = tid; i < ntile; i += kBinBlock) {
         hist[i] = 0;
+        n_both[i] = 0;
+        n_even[i] = 0;
         bb_rmin[i] = kTile;
         bb_cmin[i] = kTile;
         bb_rmax[i] = 0;
         bb_cmax[i] = 0;
     }
-    for (int i = tid; i < job.hash_size; i += kBlock) {
+    for (int i = tid; i < job.hash_size; i += kBinBlock) {
         hkey[i] = 0;
         hval[i] = 0;
     }
     __syncthreads();
 
-    /* Pass A: beams that land on the same cell of this slice contribute the
-     * same value to every candidate, so they are merged: a small LDS hash
-     * table counts the beams per (tile, cell). */
+    /* Pass A: count the beams per (tile, cell) -- per (tile, row pair, column)
+     * in pair mode -- and the bounding box of the hit cells per tile. */
     const int r_max = job.rows - 1 - job.y_lo;
     const int c_max = job.cols - 1 - job.x_lo;
     bool band = false;
-    for (int i = tid; i < n; i += kBlock) {
+    for (int i = tid; i < n; i += kBinBlock) {
         const int r = row[i], c = col[i];
         const int rr = r + job.y_hi, cc = c + job.x_hi;
         if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
@@ -126,12 +151,13 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             atomicMax(&bb_rmax[tile], rb);
             atomicMin(&bb_cmin[tile], cb);
             atomicMax(&bb_cmax[tile], cb);
-            const uint32_t key = (((uint32_t)tile << 12) | (rb << 6) | cb) + 1u;
+            const uint32_t rkey = pairs ? rb >> 1 : rb;
+            const uint32_t key = (((uint32_t)tile << 12) | (rkey << 6) | cb) + 1u;
             uint32_t slot = (key * 2654435761u) >> 12 & hmask;
             while (true) {
                 const uint32_t old = atomicCAS(&hkey[slot], 0u, key);
                 if (old == 0u || old == key) {
-                    atomicAdd(&hval[slot], 1u);
+                    atomicAdd(&hval[slot], (pairs && (rb & 1u)) ? 0x10000u : 1u);
                     break;
                 }
                 slot = (slot + 1u) & hmask;
@@ -150,18 +176,26 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
 
     /* the host decides per query whether merging pays (job.max_mult 1 = off) */
     const uint32_t max_mult = (uint32_t)job.max_mult;
+    auto chunks = [&](uint32_t beams) { return (beams + max_mult - 1u) / max_mult; };
 
-    /* Pass B: entries per tile (a cell with more than max_mult beams is split) */
-    for (int sl = tid; sl < job.hash_size; sl += kBlock) {
+    /* Pass B: entries per tile and class (a cell with more than max_mult beams is split) */
+    for (int sl = tid; sl < job.hash_size; sl += kBinBlock) {
         const uint32_t key = hkey[sl];
-        if (key)
-            atomicAdd(&hist[(key - 1u) >> 12],
-                      max_mult == 1u ? hval[sl] : (hval[sl] + kMaxMult - 1) / kMaxMult);
+        if (!key)
+            continue;
+        const uint32_t ce = chunks(hval[sl] & 0xffffu), co = chunks(hval[sl] >> 16);
+        const uint32_t both = min(ce, co);
+        const int tile = (int)((key - 1u) >> 12);
+        atomicAdd(&hist[tile], max(ce, co));
+        if (both)
+            atomicAdd(&n_both[tile], both);
+        if (ce > both)
+            atomicAdd(&n_even[tile], ce - both);
     }
     __syncthreads();
 
     /* exclusive scan of entry counts and of the records per tile */
-    const int chunk = (ntile + kBlock - 1) / kBlock;
+    const int chunk = (ntile + kBinBlock - 1) / kBinBlock;
     const int lo = tid * chunk, hi = min(lo + chunk, ntile);
     uint32_t cnt = 0, ne = 0;
     for (int i = lo; i < hi; ++i) {
@@ -180,7 +214,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
                 b += ub;
             }
         }
-        __shared__ uint32_t wtot[2][kBlock / 64];
+        __shared__ uint32_t wtot[2][kBinBlock / 64];
         if (ln == 63) {
             wtot[0][tid >> 6] = a;
             wtot[1][tid >> 6] = b;
@@ -192,64 +226,112 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             bb2 += wtot[1][w];
         }
         part[tid] = ba + a - cnt;
-        part[kBlock + tid] = bb2 + b - ne;
-        if (tid == kBlock - 1)
+        part[kBinBlock + tid] = bb2 + b - ne;
+        if (tid == kBinBlock - 1)
             job.n_tiles[t] = (int32_t)(bb2 + b);
     }
     __syncthreads();
-    uint32_t off = part[tid], slot_rec = part[kBlock + tid];
+    uint32_t off = part[tid], slot_rec = part[kBinBlock + tid];
     TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     for (int i = lo; i < hi; ++i) {
         const uint32_t c = hist[i];
+        const uint32_t nb = n_both[i], nev = n_even[i];
         first[i] = off;
+        const int rmin = pairs ? (int)(bb_rmin[i] & ~1u) : (int)bb_rmin[i];
         for (uint32_t done = 0; done < c; done += kPbMax) {
             TileRec rec;
-            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi + (int)bb_rmin[i];
+            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi + rmin;
             rec.c0 = (i % job.tiles_x) * kTile - job.x_hi + (int)bb_cmin[i];
             rec.start = off + done;
             rec.count = min(c - done, (uint32_t)kPbMax);
-            rec.h = (int)(bb_rmax[i] - bb_rmin[i]) + 1;
+            rec.h = (int)bb_rmax[i] - rmin + 1;
             rec.w = (int)(bb_cmax[i] - bb_cmin[i]) + 1;
-            rec.pad[0] = rec.pad[1] = 0;
+            /* class counts of this chunk: entries [done, done + count) of the tile's
+             * list [both | even only | odd only] */
+            const uint32_t end = done + rec.count;
+            rec.pad[0] = (int)(min(end, nb) - min(done, nb));
+            rec.pad[1] = (int)(min(end, nb + nev) - min(max(done, nb), nb + nev));
             recs[slot_rec++] = rec;
         }
         off += c;
     }
     __syncthreads();
-    for (int i = lo; i < hi; ++i)
-        hist[i] = first[i];
+    /* cursors: both | even only | odd only */
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t f = first[i], nb = n_both[i], nev = n_even[i];
+        hist[i] = f;
+        n_both[i] = f + nb;          /* even-only cursor */
+        n_even[i] = f + nb + nev;    /* odd-only cursor */
+    }
     __syncthreads();
 
-    /* Pass C: one entry per (cell, <= kMaxMult beams): offset inside the
-     * tile's bounding box + multiplicity.
-     *   sorted_pb: mult << 16 | (row * lstride + col)       (stride-1 jobs)
-     *   sorted_rc: mult << 24 | row << 16 | col             (strided jobs)  */
+    /* Pass C: the entries */
     uint32_t* out = job.sorted_pb + (size_t)t * n;
     uint32_t* out_rc = job.sorted_rc ? job.sorted_rc + (size_t)t * n : nullptr;
-    for (int sl = tid; sl < job.hash_size; sl += kBlock) {
+    for (int sl = tid; sl < job.hash_size; sl += kBinBlock) {
         const uint32_t key = hkey[sl];
         if (!key)
             continue;
         const uint32_t k1 = key - 1u;
         const int tile = (int)(k1 >> 12);
-        const uint32_t rb = ((k1 >> 6) & 63u) - bb_rmin[tile];
+        const uint32_t rmin = pairs ? bb_rmin[tile] & ~1u : bb_rmin[tile];
+        const uint32_t rkey = (k1 >> 6) & 63u;
+        const uint32_t rb = (pairs ? rkey << 1 : rkey) - rmin;      /* even in pair mode */
         const uint32_t cb = (k1 & 63u) - bb_cmin[tile];
-        uint32_t beams = hval[sl];
-        const uint32_t entries = max_mult == 1u ? beams : (beams + kMaxMult - 1) / kMaxMult;
-        uint32_t pos = atomicAdd(&hist[tile], entries);
-        for (; beams > 0; ++pos) {
-            const uint32_t m = min(beams, max_mult);
-            beams -= m;
-            out[pos] = (m << 16) | (rb * (uint32_t)job.lstride + cb);
+        uint32_t be = hval[sl] & 0xffffu, bo = hval[sl] >> 16;
+        const uint32_t ce = chunks(be), co = chunks(bo);
+        const uint32_t both = min(ce, co);
+        uint32_t pos_b = both ? atomicAdd(&hist[tile], both) : 0u;
+        uint32_t pos_x = 0;
+        if (ce > both)
+            pos_x = atomicAdd(&n_both[tile], ce - both);
+        else if (co > both)
+            pos_x = atomicAdd(&n_even[tile], co - both);
+        const uint32_t total = max(ce, co);
+        for (uint32_t k = 0; k < total; ++k) {
+            const uint32_t me = min(be, max_mult), mo = min(bo, max_mult);
+            be -= me;
+            bo -= mo;
+            const uint32_t pos = (me && mo) ? pos_b++ : pos_x++;
+            if (pairs)
+                out[pos] = (mo << 20) | (me << 16) | ((rb >> 1) * 2u * (uint32_t)job.lstride + 2u * cb);
+            else
+                out[pos] = (me << 16) | (rb * (uint32_t)job.lstride + cb);
             if (out_rc)
-                out_rc[pos] = (m << 24) | (rb << 16) | cb;
+                out_rc[pos] = (mo << 28) | (me << 24) | (rb << 16) | cb;
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_bin(BinJob job)
+__global__ __launch_bounds__(kBinBlock) void k_bin(BinJob job)
 {
     k_bin_body(job);
+}
+
+/* Clears the coarse level's atomic accumulators of a query, but only when some
+ * beam can reach the negative edge band (or `always`): otherwise the coarse
+ * pass exits without touching them (ScoreJob.skip_unless_band). One workgroup
+ * column per query; replaces 27 MB of unconditional clearing per 64-window
+ * launch. */
+__device__ __forceinline__ void zero_body(const ZeroJob& z)
+{
+    if (!z.always && !(*z.flags & kFlagBandTouch))
+        return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < z.words; i += (size_t)gridDim.x * 256) {
+        z.a[i] = 0;
+        if (z.b)
+            z.b[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zero_if_band(ZeroJob job)
+{
+    zero_body(job);
+}
+
+__global__ __launch_bounds__(256) void k_zero_if_band_batch(const ZeroJob* jobs)
+{
+    zero_body(jobs[blockIdx.y]);
 }
 
 /* ------------------------------------------------------------------ K1 */
@@ -278,6 +360,129 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+/* Shared tail of the scoring kernels: dumps, tile-split accumulation,
+ * eligibility against the coarser levels, bound check, wave64 arg-max, one
+ * record per workgroup. S / K: this lane's exact sums for its R candidates
+ * (rows by * cby + g * R + r, column bx * cbx + dxi). */
+template <int R>
+__device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S)[R], uint32_t (&K)[R],
+                                               int t, int bx, int by, int cbx, int cby, int g, int dxi,
+                                               bool lane_on, uint32_t qflags)
+{
+    __shared__ unsigned long long red_key[kBlock / 64];
+    __shared__ unsigned long long red_rank[kBlock / 64];
+    __shared__ uint32_t red_cnt[kBlock / 64];
+    const int tid = threadIdx.x;
+    const int xi = bx * cbx + dxi;
+    if (job.in_s && lane_on && xi < job.nx) {
+        /* arg-max pass of a tile-split launch: the slices' sums are complete */
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yi = by * cby + g * R + r;
+            if (yi < job.ny) {
+                const size_t ai = ((size_t)t * job.ny + yi) * job.nx + xi;
+                S[r] = job.in_s[ai];
+                K[r] = job.in_k[ai];
+                /* leave the accumulators clean for the next query */
+                job.in_s[ai] = 0;
+                job.in_k[ai] = 0;
+            }
+        }
+    }
+    unsigned long long bkey = 0, brank = ~0ull;
+    uint32_t bcnt = 0;
+    bool bound_broken = false;
+    const bool band_touch =
+        (job.block_best || job.tie_list) && job.n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
+    if (lane_on && xi < job.nx) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yi = by * cby + g * R + r;
+            if (yi >= job.ny)
+                continue;
+            const size_t ci = ((size_t)t * job.nx + xi) * job.ny + yi;
+            if (job.dump_s)
+                job.dump_s[ci] = S[r];
+            if (job.dump_k)
+                job.dump_k[ci] = (uint16_t)K[r];
+            if (job.acc_s) {
+                /* tile-split launch: slices add their partial integer sums.
+                 * acc_x_major: consecutive lanes (dx) hit consecutive words */
+                const size_t ai = job.acc_x_major ? ((size_t)t * job.ny + yi) * job.nx + xi : ci;
+                if (S[r])
+                    atomicAdd(&job.acc_s[ai], S[r]);
+                if (K[r])
+                    atomicAdd(&job.acc_k[ai], K[r]);
+            }
+            if (!job.block_best && !job.tie_list)
+                continue;
+            const bool use_elig = !job.elig_only_if_band || (qflags & kFlagBandTouch);
+            bool ok = !(job.check_own_known || !use_elig) || (int)K[r] >= job.min_known;
+            const unsigned long long key =
+                32268ull * K[r] + 499ull * (unsigned long long)S[r];
+            bool broken = false;
+            for (int e = 0; e < job.n_elig && ok && use_elig; ++e) {
+                const EligLevel& el = job.elig[e];
+                const size_t ni =
+                    ((size_t)t * el.nxc + xi / el.div) * el.nyc + yi / el.div;
+                const uint32_t ck = el.k[ni];
+                ok = (int)ck >= job.min_known;
+                /* the coarser node must bound this candidate; it can fail to
+                 * only through the negative edge band (SURVEY 8(a) A8) */
+                const unsigned long long ckey =
+                    32268ull * ck + 499ull * (unsigned long long)el.s[ni];
+                broken |= key > ckey || (key == ckey && band_touch);
+            }
+            if (!ok)
+                continue;
+            bound_broken |= broken;
+            if (key == 0)
+                continue;
+            if (job.tie_list && key != *job.collect_key)
+                continue;
+            const int L = job.rank_l;
+            const int nxc = job.nx / L, nyc = job.ny / L;
+            const unsigned long long rank =
+                ((((unsigned long long)t * nxc + xi / L) * nyc + yi / L) * L + xi % L) * L + yi % L;
+            if (job.tie_list) {
+                const uint32_t pos = atomicAdd(job.tie_count, 1u);
+                if (pos < job.tie_cap)
+                    job.tie_list[pos] = rank;
+                continue;
+            }
+            best_combine(bkey, brank, bcnt, key, rank, 1u);
+        }
+    }
+    if (!job.block_best)
+        return;
+    if (bound_broken)
+        atomicOr(job.flags, CSM_FLAG_EDGE_BAND);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long k2 = shfl_xor_u64(bkey, m);
+        const unsigned long long r2 = shfl_xor_u64(brank, m);
+        const uint32_t c2 = __shfl_xor(bcnt, m, 64);
+        best_combine(bkey, brank, bcnt, k2, r2, c2);
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+        red_key[wave] = bkey;
+        red_rank[wave] = brank;
+        red_cnt[wave] = bcnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            best_combine(bkey, brank, bcnt, red_key[w], red_rank[w], red_cnt[w]);
+        BlockBest bb;
+        bb.key = bkey;
+        bb.rank = brank;
+        bb.count = bcnt;
+        bb.pad = 0;
+        job.block_best[(size_t)t * gridDim.x + blockIdx.x] = bb;
+    }
+}
+
 /* LSTRIDE: LDS row pitch in cells. R: candidate rows per lane.
  * MODE 0: candidates one cell apart; 1: `stride` = 2^k cells apart (coarser
  * levels); 2: any stride (e.g. LowResolutionMapWinSize 5).
@@ -288,9 +493,6 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                                            int slice, int n_slices, int n_buf)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
-    __shared__ unsigned long long red_key[kBlock / 64];
-    __shared__ unsigned long long red_rank[kBlock / 64];
-    __shared__ uint32_t red_cnt[kBlock / 64];
 
     const int t = blockIdx.y;
     if (t >= job.n_theta)
@@ -491,22 +693,11 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
         const int a = (cur.c0 + x0) & 7;
         const int cnt = (int)cur.count;
         const uint32_t* base = sm_cells + tb + a;
-        /* entry = cell offset + number of beams on that cell (<= kMaxMult) */
-        auto locate = [&](uint32_t pbv) -> const uint32_t* {
-            uint32_t off;
-            if (STRIDED) {
-                /* pbv = mult << 24 | row << 16 | col inside the bounding box */
-                const uint32_t rb = (pbv >> 16) & 0xffu, cbm = (pbv & 0xffffu) + (uint32_t)a;
-                off = (smod(rb) * hd + sdiv(rb)) * LSTRIDE + smod(cbm) * wd + sdiv(cbm);
-            } else {
-                off = pbv & 0xffffu;
-            }
-            return (STRIDED ? sm_cells + tb : base) + off;
-        };
-        auto gather = [&](uint32_t pbv) {
-            const uint32_t* p = locate(pbv);
+        /* entry = cell offset + number of beams on that cell (<= kMaxMult);
+         * strided jobs read k_bin's sorted_rc words: m_odd << 28 | m_even << 24 |
+         * row << 16 | col inside the bounding box, m_odd beams on the row below */
+        auto gather_at = [&](const uint32_t* p, uint32_t m) {
             if (WEIGHTED) {                        /* weighted by the beam count */
-                const uint32_t m = STRIDED ? pbv >> 24 : pbv >> 16;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     acc[r] = mad_u24(p[r * LSTRIDE], m, acc[r]);
@@ -516,8 +707,24 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
                     acc[r] += p[r * LSTRIDE];
             }
         };
+        auto gather = [&](uint32_t pbv) {
+            if (STRIDED) {
+                const uint32_t cbm = (pbv & 0xffffu) + (uint32_t)a;
+                const uint32_t coff = smod(cbm) * wd + sdiv(cbm);
+                const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
+                uint32_t rb = (pbv >> 16) & 0xffu;
+                if (me)
+                    gather_at(sm_cells + tb + (smod(rb) * hd + sdiv(rb)) * LSTRIDE + coff, me);
+                if (mo) {
+                    ++rb;
+                    gather_at(sm_cells + tb + (smod(rb) * hd + sdiv(rb)) * LSTRIDE + coff, mo);
+                }
+            } else {
+                gather_at(base + (pbv & 0xffffu), pbv >> 16);
+            }
+        };
         auto mult_of = [&](uint32_t pbv) {
-            return !WEIGHTED ? 1u : STRIDED ? pbv >> 24 : pbv >> 16;
+            return STRIDED ? ((pbv >> 24) & 15u) + (pbv >> 28) : !WEIGHTED ? 1u : pbv >> 16;
         };
         /* entries: 64 per LDS read, broadcast with v_readlane */
         uint32_t pb_cur = lpb[lane];
@@ -552,115 +759,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     }
     flush();
 
-    /* ---- epilogue: dumps, eligibility, arg-max ---- */
-    const int xi = bx * cbx + dxi;
-    if (job.in_s && lane_on && xi < job.nx) {
-        /* arg-max pass of a tile-split launch: the slices' sums are complete */
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int yi = by * cby + g * R + r;
-            if (yi < job.ny) {
-                const size_t ai = ((size_t)t * job.ny + yi) * job.nx + xi;
-                S[r] = job.in_s[ai];
-                K[r] = job.in_k[ai];
-                /* leave the accumulators clean for the next query */
-                job.in_s[ai] = 0;
-                job.in_k[ai] = 0;
-            }
-        }
-    }
-    unsigned long long bkey = 0, brank = ~0ull;
-    uint32_t bcnt = 0;
-    bool bound_broken = false;
-    const bool band_touch =
-        (job.block_best || job.tie_list) && job.n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
-    if (lane_on && xi < job.nx) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int yi = by * cby + g * R + r;
-            if (yi >= job.ny)
-                continue;
-            const size_t ci = ((size_t)t * job.nx + xi) * job.ny + yi;
-            if (job.dump_s)
-                job.dump_s[ci] = S[r];
-            if (job.dump_k)
-                job.dump_k[ci] = (uint16_t)K[r];
-            if (job.acc_s) {
-                /* tile-split launch: slices add their partial integer sums.
-                 * acc_x_major: consecutive lanes (dx) hit consecutive words */
-                const size_t ai = job.acc_x_major ? ((size_t)t * job.ny + yi) * job.nx + xi : ci;
-                if (S[r])
-                    atomicAdd(&job.acc_s[ai], S[r]);
-                if (K[r])
-                    atomicAdd(&job.acc_k[ai], K[r]);
-            }
-            if (!job.block_best && !job.tie_list)
-                continue;
-            const bool use_elig = !job.elig_only_if_band || (qflags & kFlagBandTouch);
-            bool ok = !(job.check_own_known || !use_elig) || (int)K[r] >= job.min_known;
-            const unsigned long long key =
-                32268ull * K[r] + 499ull * (unsigned long long)S[r];
-            bool broken = false;
-            for (int e = 0; e < job.n_elig && ok && use_elig; ++e) {
-                const EligLevel& el = job.elig[e];
-                const size_t ni =
-                    ((size_t)t * el.nxc + xi / el.div) * el.nyc + yi / el.div;
-                const uint32_t ck = el.k[ni];
-                ok = (int)ck >= job.min_known;
-                /* the coarser node must bound this candidate; it can fail to
-                 * only through the negative edge band (SURVEY 8(a) A8) */
-                const unsigned long long ckey =
-                    32268ull * ck + 499ull * (unsigned long long)el.s[ni];
-                broken |= key > ckey || (key == ckey && band_touch);
-            }
-            if (!ok)
-                continue;
-            bound_broken |= broken;
-            if (key == 0)
-                continue;
-            if (job.tie_list && key != *job.collect_key)
-                continue;
-            const int L = job.rank_l;
-            const int nxc = job.nx / L, nyc = job.ny / L;
-            const unsigned long long rank =
-                ((((unsigned long long)t * nxc + xi / L) * nyc + yi / L) * L + xi % L) * L + yi % L;
-            if (job.tie_list) {
-                const uint32_t pos = atomicAdd(job.tie_count, 1u);
-                if (pos < job.tie_cap)
-                    job.tie_list[pos] = rank;
-                continue;
-            }
-            best_combine(bkey, brank, bcnt, key, rank, 1u);
-        }
-    }
-    if (!job.block_best)
-        return;
-    if (bound_broken)
-        atomicOr(job.flags, CSM_FLAG_EDGE_BAND);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned long long k2 = shfl_xor_u64(bkey, m);
-        const unsigned long long r2 = shfl_xor_u64(brank, m);
-        const uint32_t c2 = __shfl_xor(bcnt, m, 64);
-        best_combine(bkey, brank, bcnt, k2, r2, c2);
-    }
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
-        red_key[wave] = bkey;
-        red_rank[wave] = brank;
-        red_cnt[wave] = bcnt;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < kBlock / 64; ++w)
-            best_combine(bkey, brank, bcnt, red_key[w], red_rank[w], red_cnt[w]);
-        BlockBest bb;
-        bb.key = bkey;
-        bb.rank = brank;
-        bb.count = bcnt;
-        bb.pad = 0;
-        job.block_best[(size_t)t * gridDim.x + blockIdx.x] = bb;
-    }
+    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags);
 }
 
 /* grid = (candidate blocks, theta slices, tile slices) */
@@ -686,6 +785,300 @@ __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, in
 {
     score_body<LSTRIDE, R, MODE, WEIGHTED>(jobs[blockIdx.z / n_slices], cbx, groups,
                                     blockIdx.z % n_slices, n_slices, n_buf);
+}
+
+/* ------------------------------------------------------------------ K1, pair-row layout */
+
+/* ds_read_b64 with an immediate byte offset, issued by hand. The compiler does
+ * not know that the result arrives later: every use must sit behind lds_wait,
+ * which takes the registers as in/out operands so that nothing that reads them
+ * can be scheduled above the wait. */
+template <int OFFSET>
+__device__ __forceinline__ void lds_read_b64(uint32_t addr, unsigned long long& q)
+{
+    static_assert(OFFSET >= 0 && OFFSET < 65536, "ds offset field");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"(OFFSET));
+}
+
+/* s_waitcnt lgkmcnt(LATER): returns once all LDS reads but the LATER youngest
+ * have landed (LDS returns in order; an interleaved scalar load or a read the
+ * compiler issued only makes the wait longer, never shorter). */
+template <int LATER, int N>
+__device__ __forceinline__ void lds_wait(unsigned long long (&q)[N])
+{
+    static_assert(N == 2 || N == 3 || N == 4 || N == 5, "registers to tie");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]) : "n"(LATER));
+    else if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(LATER));
+    else if constexpr (N == 3)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) : "n"(LATER));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "n"(LATER));
+}
+
+/* The fine level (candidates one cell apart) with the LDS region stored in
+ * ROW PAIRS: the 8-byte slot (pair row k, column c) holds the expanded cells of
+ * region rows 2k and 2k + 1 at column c. A lane still owns one candidate column
+ * and R (even) consecutive candidate rows, but fetches its cells with
+ * ds_read_b64 -- twice the bytes per LDS cycle of ds_read_b32 -- and one entry
+ * of k_bin's pair mode (an aligned row pair of one column with a beam count per
+ * row) needs R/2 reads (even row only) or R/2 + 1 (odd row / both) for R or 2R
+ * multiply-adds, instead of R reads per R.
+ *
+ * LS = slots per pair row. A half-wave straddles two lane groups unless cbx is
+ * a multiple of 32; the reads of such a half-wave stay conflict-free when
+ * (R/2) * LS == cbx (mod 32) (the second group's slots continue where the
+ * first group's end), which is how the host picks LS (plan_pass_pairs).
+ *
+ * Staging: lane pairs (2q, 2q + 1) fetch the two rows of one 2-column chunk
+ * (one dword each, 256 contiguous bytes per row and wave), expand the cells to
+ * v + (v != 0) << 23 and store them with two ds_write_b32 (2-way bank pattern:
+ * free for stores). Entries arrive sorted by class, TileRec.pad = class counts. */
+template <int LS, int R, bool WEIGHTED>
+__device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, int groups, int slice,
+                                                 int n_slices)
+{
+    static_assert(R % 2 == 0, "pair rows");
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
+    const int t = blockIdx.y;
+    if (t >= job.n_theta)
+        return;
+    const int tid = threadIdx.x;
+    const int ncbx = (job.nx + cbx - 1) / cbx;
+    const int bx = blockIdx.x % ncbx, by = blockIdx.x / ncbx;
+    const int cby = groups * R;
+    if (by * cby >= job.ny)
+        return;
+    const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
+
+    const int dxi = tid % cbx, g = tid / cbx;
+    const bool lane_on = g < groups;
+    const int x0 = job.x_lo + bx * cbx;
+    const int y0 = job.y_lo + by * cby;
+    constexpr int PR = 2 * LS;                          /* dwords per pair row */
+    const int max_prows = (kTile + cby) / 2 + 1;
+    uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
+    uint32_t* lpb = sm_cells + max_prows * PR;
+    const int tb = lane_on ? (g * (R / 2)) * PR + 2 * dxi : 0;
+    const int lane = tid & 63;
+
+    uint32_t S[R], K[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        S[r] = 0;
+        K[r] = 0;
+        acc[r] = 0;
+    }
+    int pending = 0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S[r] += acc[r] & 0x7fffffu;
+            K[r] += acc[r] >> 23;
+            acc[r] = 0;
+        }
+        pending = 0;
+    };
+
+    const int grid_rows = job.rows, grid_pitch = job.pitch;
+    const uint16_t* __restrict__ cells = job.cells;
+    const int ntiles = job.in_s ? 0 : job.n_tiles[t];
+    const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
+    const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)t * job.n_points;
+    /* staging units (one dword = 2 cells of one row) a lane may have to fetch per tile */
+    constexpr int kMaxU = (((kTile + kPairMaxCby) / 2 + 1) * 2 * ((LS + 1) / 2) + kBlock - 1) / kBlock;
+    constexpr int kPbRegs = kPbMax / kBlock;
+
+    uint32_t pre[kMaxU];
+    uint32_t pre_pb[kPbRegs];
+    int nch = 1, total = 0;            /* 2-column chunks per row; lane pairs' units in all */
+    int pr0 = 0, ch0 = 0, dq = 0, dr = 0;
+    TileRec rec;
+    const int half = tid >> 1, rpar = tid & 1;
+    auto fetch = [&](const TileRec& tr) {
+        const int cs = (tr.c0 + x0) & ~1;                /* dword aligned first column */
+        const int a = (tr.c0 + x0) - cs;                 /* 0..1 */
+        const int nprows = (tr.h + cby) >> 1;            /* rows 0 .. h + cby - 2, rounded up to pairs */
+        nch = (a + tr.w + (cbx - 1) + 1) >> 1;
+        total = nprows * nch;
+        const int gr0 = tr.r0 + y0;
+        /* unit q = half + k * (kBlock / 2) -> (pair row, chunk), stepped without a division */
+        pr0 = half / nch;
+        ch0 = half - pr0 * nch;
+        dq = (kBlock / 2) / nch;
+        dr = (kBlock / 2) - dq * nch;
+        int pr = pr0, ch = ch0;
+#pragma unroll
+        for (int k = 0; k < kMaxU; ++k) {
+            const int q = half + k * (kBlock / 2);
+            const int gr = gr0 + 2 * pr + rpar, gc = cs + 2 * ch;
+            const bool ok = q < total && gr >= 0 && gr < grid_rows && gc >= 0 && gc < grid_pitch;
+            uint32_t v = 0;
+            if (ok)
+                v = *reinterpret_cast<const uint32_t*>(cells + (size_t)gr * grid_pitch + gc);
+            pre[k] = v;
+            pr += dq;
+            ch += dr;
+            if (ch >= nch) {
+                ch -= nch;
+                ++pr;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kPbRegs; ++q) {
+            const uint32_t bi = tid + q * kBlock;
+            pre_pb[q] = bi < tr.count ? pbs[tr.start + bi] : 0u;
+        }
+    };
+    auto expand = [](uint32_t v) { return v + (min(v, 1u) << 23); };
+
+    int ti = slice;
+    if (ti < ntiles) {
+        rec = recs[ti];
+        fetch(rec);
+    }
+    for (; ti < ntiles; ti += n_slices) {
+        __syncthreads();                                 /* previous tile consumed */
+        {
+            int pr = pr0, ch = ch0;
+#pragma unroll
+            for (int k = 0; k < kMaxU; ++k) {
+                if (half + k * (kBlock / 2) < total) {
+                    const uint32_t w = pre[k];
+                    uint32_t* dst = sm_cells + pr * PR + 4 * ch + rpar;
+                    dst[0] = expand(w & 0xffffu);
+                    dst[2] = expand(w >> 16);
+                }
+                pr += dq;
+                ch += dr;
+                if (ch >= nch) {
+                    ch -= nch;
+                    ++pr;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kPbRegs; ++q)
+            lpb[tid + q * kBlock] = pre_pb[q];
+        __syncthreads();
+        /* wave-uniform values, told to the compiler as such: the entry loops then run
+         * on scalar registers and scalar branches */
+        const int a = __builtin_amdgcn_readfirstlane((rec.c0 + x0) & 1);
+        const int cnt = __builtin_amdgcn_readfirstlane((int)rec.count);
+        const int end_both = __builtin_amdgcn_readfirstlane(rec.pad[0]);
+        const int end_even = end_both + __builtin_amdgcn_readfirstlane(rec.pad[1]);
+        if (ti + n_slices < ntiles) {
+            rec = recs[ti + n_slices];
+            fetch(rec);
+        }
+        /* One entry: `pbv` = m_odd << 20 | m_even << 16 | dword offset of its first slot.
+         * CLS 0: both rows hit, 1: even row only, 2: odd row only. The reads are
+         * hand-issued ds_read_b64 (the compiler would fuse two of them into a
+         * ds_read2_b64, which runs at half the rate) and software-pipelined: the
+         * next entry's reads are in flight while this entry's multiply-adds run. */
+        const uint32_t lane_addr = (uint32_t)(tb + 2 * a) * 4u;      /* byte address of the lane's slot */
+        auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
+            constexpr int CLS = decltype(cls)::value;
+            const uint32_t addr = lane_addr + ((pbv & 0xffffu) << 2);
+            lds_read_b64<0 * LS * 8>(addr, q[0]);
+            lds_read_b64<1 * LS * 8>(addr, q[1]);
+            if (R >= 6)
+                lds_read_b64<2 * LS * 8>(addr, q[2]);
+            if (R >= 8)
+                lds_read_b64<3 * LS * 8>(addr, q[3]);
+            if (CLS != 1)
+                lds_read_b64<(R / 2) * LS * 8>(addr, q[R / 2]);
+        };
+        auto mads = [&](uint32_t pbv, auto cls, const unsigned long long (&q)[R / 2 + 1]) {
+            constexpr int CLS = decltype(cls)::value;
+            uint32_t v[R + 2];
+#pragma unroll
+            for (int i = 0; i < R / 2 + 1; ++i) {
+                v[2 * i] = (uint32_t)q[i];
+                v[2 * i + 1] = (uint32_t)(q[i] >> 32);
+            }
+            const uint32_t me = (pbv >> 16) & 15u, mo = pbv >> 20;
+            const int mm = (int)(me + mo);
+            if (pending + mm > 128)
+                flush();
+            pending += mm;
+            if (WEIGHTED) {
+                /* the two multiply-adds of one accumulator are kept R instructions
+                 * apart: back to back the compiler pads them with s_nop */
+                if (CLS != 2) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[r] = mad_u24(v[r], me, acc[r]);
+                }
+                if (CLS != 1) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[r] = mad_u24(v[r + 1], mo, acc[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (CLS == 0)
+                        acc[r] += v[r] + v[r + 1];       /* v_add3_u32 */
+                    else
+                        acc[r] += v[CLS == 1 ? r : r + 1];
+                }
+            }
+        };
+        /* entries [j, end) of one class; 64 entries per LDS read, broadcast with v_readlane */
+        int j = 0;
+        uint32_t pb_cur = lpb[lane];
+        auto run = [&](int end, auto cls) {
+            constexpr int CLS = decltype(cls)::value;
+            constexpr int NP = CLS == 1 ? R / 2 : R / 2 + 1;     /* reads per entry */
+            while (j < end) {
+                const int stop = min(end, (j | 63) + 1);
+                unsigned long long qa[R / 2 + 1], qb[R / 2 + 1];
+                uint32_t oa = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63), ob = 0;
+                issue(oa, cls, qa);
+                for (; j + 2 <= stop; j += 2) {
+                    ob = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
+                    issue(ob, cls, qb);
+                    lds_wait<NP, R / 2 + 1>(qa);              /* all but the NP reads just issued */
+                    mads(oa, cls, qa);
+                    if (j + 2 < stop) {
+                        oa = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
+                        issue(oa, cls, qa);
+                        lds_wait<NP, R / 2 + 1>(qb);
+                    } else {
+                        lds_wait<0, R / 2 + 1>(qb);
+                    }
+                    mads(ob, cls, qb);
+                }
+                if (j < stop) {
+                    lds_wait<0, R / 2 + 1>(qa);
+                    mads(oa, cls, qa);
+                    ++j;
+                }
+                if ((j & 63) == 0 && j < cnt)
+                    pb_cur = lpb[j + lane];
+            }
+        };
+        run(end_both, std::integral_constant<int, 0>());
+        run(end_even, std::integral_constant<int, 1>());
+        run(cnt, std::integral_constant<int, 2>());
+    }
+    flush();
+    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+}
+
+template <int LS, int R, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups)
+{
+    score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z);
+}
+
+/* grid = (candidate blocks, theta slices, jobs) */
+template <int LS, int R, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups)
+{
+    score_body_pairs<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, 0, 1);
 }
 
 /* ------------------------------------------------------------------ K2 */
@@ -1123,7 +1516,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_pick(GridSearchJob job)
 }
 
 /* ------------------------------------------------------------------ batch */
-__global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
+__global__ __launch_bounds__(kBinBlock) void k_bin_batch(const BinJob* jobs)
 {
     /* k_bin reads blockIdx.x as the theta slice */
     k_bin_body(jobs[blockIdx.y]);
@@ -1132,6 +1525,21 @@ __global__ __launch_bounds__(kBlock) void k_bin_batch(const BinJob* jobs)
 __global__ __launch_bounds__(kBlock) void k_finalize_batch(const FinalJob* jobs)
 {
     k_finalize_body(jobs[blockIdx.x]);
+}
+
+/* dst[idx[i]] = src[i]: the records of one shape group into query order */
+__global__ __launch_bounds__(256) void k_scatter_records(const csm_result* src, const int32_t* idx,
+                                                        csm_result* dst, int n)
+{
+    static_assert(sizeof(csm_result) == 48, "record layout");
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint4* s = reinterpret_cast<const uint4*>(src + i);
+    uint4* d = reinterpret_cast<uint4*>(dst + idx[i]);
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
 }
 
 /* Bound on |q_host - q_device| for q = (sensor + r*trig - off) / res, in

@@ -34,6 +34,9 @@
 #include <deque>
 #include <queue>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 extern "C" {
 
@@ -341,6 +344,105 @@ int orc_csm(const uint16_t* grid, const uint16_t* coarse, int rows, int cols,
     out->bestT = bestT;
     out->scoreMax = scoreMax;
     finish_pose(s, out);
+    return 0;
+}
+
+/* The same sweep with the theta loop spread over all host cores (OpenMP): the
+ * all-core CPU baseline of BASELINE.md section 4(b). Every theta slice runs the
+ * literal x / y sweep of orc_csm with a running maximum of its own plus a
+ * shared bound (the best score any slice has found so far, tested strictly);
+ * the slices' winners are then merged in theta order with the same strict `<`.
+ * Same winner as orc_csm whenever the closed form of A5 holds (no edge band).
+ * `threads` receives the number of OpenMP threads actually used. */
+int orc_csm_omp(const uint16_t* grid, const uint16_t* coarse, int rows, int cols,
+                const double* geom, const double* angles, const double* ranges, int n,
+                const double* rel, const double* init,
+                const OrcCsmParams* p, OrcResult* out, int* threads)
+{
+    Grid g { grid, rows, cols, geom[0], geom[1], geom[2] };
+    Grid gc { coarse, rows, cols, geom[0], geom[1], geom[2] };
+    OrcScan s { angles, ranges, n, { rel[0], rel[1], rel[2] } };
+    const double* lut = shared_lut();
+    std::memset(out, 0, sizeof(*out));
+    setup_window(g, s, init, p->rangeX, p->rangeY, p->rangeT, out);
+    const int winX = out->winX, winY = out->winY, winT = out->winT;
+    const int L = p->lowRes;
+    const int nT = 2 * winT + 1;
+    struct Slice { double score; int x, y; long long ignored, processed, fine; };
+    std::vector<Slice> best(nT);
+    int used = 1;
+    double shared = p->scoreThr;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#endif
+        std::vector<int> col(n), row(n);
+#pragma omp for schedule(dynamic, 1)
+        for (int ti = 0; ti < nT; ++ti) {
+            const int t = ti - winT;
+            const double pose[3] = { out->sensorPose[0], out->sensorPose[1],
+                                     out->sensorPose[2] + out->stepT * t };
+            scan_indices(gc, pose, s, col.data(), row.data());
+            Slice b { p->scoreThr, -winX, -winY, 0, 0, 0 };
+            for (int x = -winX; x <= winX; x += L)
+                for (int y = -winY; y <= winY; y += L) {
+                    const ScoreSummary c =
+                        compute_score(gc, lut, col.data(), row.data(), n, x, y);
+                    /* `shared`: the best score any slice has found so far. A node
+                     * strictly below it cannot hold the global winner; equality is
+                     * kept so that the earliest theta still wins a tie. */
+                    double bound;
+#pragma omp atomic read
+                    bound = shared;
+                    if (c.normalized <= b.score || c.normalized < bound ||
+                        c.knownRate <= p->knownThr) {
+                        b.ignored++;
+                        continue;
+                    }
+                    for (int fx = x; fx < x + L; ++fx)
+                        for (int fy = y; fy < y + L; ++fy) {
+                            const ScoreSummary f = compute_score(
+                                g, lut, col.data(), row.data(), n, fx, fy);
+                            b.fine++;
+                            if (b.score < f.normalized) {
+                                b.score = f.normalized;
+                                b.x = fx;
+                                b.y = fy;
+                            }
+                        }
+                    if (b.score > bound) {
+#pragma omp critical(orc_csm_omp_bound)
+                        if (b.score > shared)
+                            shared = b.score;
+                    }
+                    b.processed++;
+                }
+            best[ti] = b;
+        }
+    }
+    double scoreMax = p->scoreThr;
+    int bestX = -winX, bestY = -winY, bestT = -winT;
+    for (int ti = 0; ti < nT; ++ti) {
+        out->ignoredNodes += best[ti].ignored;
+        out->processedNodes += best[ti].processed;
+        out->fineEvaluated += best[ti].fine;
+        if (scoreMax < best[ti].score) {
+            scoreMax = best[ti].score;
+            bestX = best[ti].x;
+            bestY = best[ti].y;
+            bestT = ti - winT;
+        }
+    }
+    out->found = scoreMax > p->scoreThr;
+    out->bestX = bestX;
+    out->bestY = bestY;
+    out->bestT = bestT;
+    out->scoreMax = scoreMax;
+    finish_pose(s, out);
+    if (threads)
+        *threads = used;
     return 0;
 }
 

@@ -169,6 +169,22 @@ def csm(case, range_x, range_y, range_t, low_res, score_thr=0.0, known_thr=0.0, 
     return out.as_dict()
 
 
+def csm_omp(case, range_x, range_y, range_t, low_res, score_thr=0.0, known_thr=0.0, coarse=None):
+    """orc_csm with the theta loop on all host cores (OpenMP). Returns the result
+    dict plus "threads" = OpenMP threads used."""
+    if coarse is None:
+        coarse = boxmax(case["grid"], low_res)
+    g, c, a, r, geom, rel, init = _csm_args(case, coarse)
+    p = CsmParams(range_x, range_y, range_t, low_res, score_thr, known_thr)
+    out = Result()
+    threads = C.c_int(0)
+    lib().orc_csm_omp(_p(g), _p(c), g.shape[0], g.shape[1], _p(geom), _p(a), _p(r), a.size,
+                      _p(rel), _p(init), C.byref(p), C.byref(out), C.byref(threads))
+    d = out.as_dict()
+    d["threads"] = threads.value
+    return d
+
+
 def csm_closed_form(case, range_x, range_y, range_t, low_res, score_thr=0.0, known_thr=0.0,
                     coarse=None, dump=False):
     if coarse is None:

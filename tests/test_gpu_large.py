@@ -92,34 +92,64 @@ def test_loop_detector_correlative_default_settings(gpu_ctx, oracle):
         gpu_ctx.release_grid(k)
 
 
-def test_config3_batch_of_256_submaps_sampled_against_oracle(gpu_ctx, oracle):
-    """configs[2]: 1 scan (1080 beams) vs 256 candidate submaps, 3-level grids
-    (H = 2), 2.5 m x 2.5 m x 0.5 rad, thresholds 0.55 / 0.6, through the sharding
-    detector class (world size 1 here). Every 16th query is checked against the
-    literal CPU search; all records must be self-consistent."""
-    n = 256
+def _loop_batch(first_seed, n, id_base):
     rng = np.random.RandomState(3)
     queries, grids, cases = [], {}, []
     for i in range(n):
-        c = synth.csm_case(1000 + i, n_beams=1080, fov=1.5 * math.pi)
+        c = synth.csm_case(first_seed + i, n_beams=1080, fov=1.5 * math.pi)
         c["init_pose"] = tuple(np.asarray(c["truth"]) + rng.uniform(-0.6, 0.6, 3) * (1, 1, 0.15))
         cases.append(c)
-        grids[20000 + i] = c["grid"]
-        queries.append(dict(map_id=20000 + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+        grids[id_base + i] = c["grid"]
+        queries.append(dict(map_id=id_base + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
                             rel_pose=(0.0, 0.0, 0.0), init_pose=c["init_pose"]))
-    det = parallel.LoopDetectorBranchBoundHIP("ld", gpu_ctx, 2.5, 2.5, 0.5, 2, 0.55, 0.6)
-    records, found = det.detect(queries, grids)
-    assert len(records) == n
+    return queries, grids, cases
+
+
+def _check_loop_records(records, found, cases, oracle, every):
     assert found == [i for i, r in enumerate(records) if r["found"]]
     for r in records:
         assert r["key"] == 32268 * r["known"] + 499 * r["sum_values"]
         if r["found"]:
             assert r["score"] > 0.55 and r["known"] / 1080 > 0.6
-    for i in range(0, n, 16):
+    for i in range(0, len(records), every):
         want = oracle.bnb(cases[i], 2.5, 2.5, 0.5, 2, 0.55, 0.6)
         r = records[i]
-        assert r["found"] == want["found"]
-        assert (r["best_x"], r["best_y"], r["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"])
-        assert r["score"] == want["scoreMax"]
+        assert r["found"] == want["found"], i
+        assert (r["best_x"], r["best_y"], r["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"]), i
+        assert r["score"] == want["scoreMax"], i
+
+
+def test_config3_batch_of_256_submaps_all_against_oracle(gpu_ctx, oracle):
+    """configs[2]: 1080-beam scans vs 256 candidate submaps, 3-level grids
+    (H = 2), 2.5 m x 2.5 m x 0.5 rad, thresholds 0.55 / 0.6, through the sharding
+    detector class (world size 1 here). EVERY query is checked against the
+    literal CPU search (std::priority_queue): found flag, best indices, f64 score."""
+    n = 256
+    queries, grids, cases = _loop_batch(1000, n, 20000)
+    det = parallel.LoopDetectorBranchBoundHIP("ld", gpu_ctx, 2.5, 2.5, 0.5, 2, 0.55, 0.6)
+    records, found = det.detect(queries, grids)
+    assert len(records) == n and len(found) > 0
+    _check_loop_records(records, found, cases, oracle, 1)
     for k in grids:
         gpu_ctx.release_grid(k)
+
+
+def test_config4_batch_of_2048_submaps_world_size_1(oracle):
+    """configs[3] at world size 1: all 2048 queries of the sharded batch through
+    LoopDetectorBranchBoundHIP.detect on one GPU (what every rank does for its
+    block), every 64th checked against the literal CPU search, all records
+    self-consistent; the device copy of the records (the all-gather's send
+    buffer, csm_copy_last_batch_records) must equal the host summaries."""
+    import torch
+    n = 2048
+    ctx = api.Context(0)
+    queries, grids, cases = _loop_batch(5000, n, 0)
+    det = parallel.LoopDetectorBranchBoundHIP("ld", ctx, 2.5, 2.5, 0.5, 2, 0.55, 0.6)
+    records, found = det.detect(queries, grids)
+    assert len(records) == n and len(found) > 0
+    _check_loop_records(records, found, cases, oracle, 64)
+    dev = torch.zeros(n * parallel.RECORD_BYTES, dtype=torch.uint8, device="cuda:0")
+    ctx.copy_last_batch_records(dev.data_ptr())
+    ctx.synchronize()
+    assert parallel.bytes_to_records(dev.cpu().numpy()) == records
+    ctx.close()
