@@ -51,6 +51,12 @@ struct DeviceGrid {
     int rows = 0, cols = 0, pitch = 0;
     int known_r0 = 0, known_c0 = 0;   /* first row / column holding a known cell */
     std::vector<Level> levels;   /* levels[0] is the uploaded grid */
+    /* expanded, zero-padded pair-row copy of level 0 for the fine kernel's LDS-DMA
+     * staging (k_expand_pairs); rebuilt when the base changes or a window needs more padding */
+    uint32_t* xg = nullptr;
+    size_t xg_cap = 0;
+    int xg_pad = 0, xg_pitch = 0;
+    bool xg_stale = true;
 };
 
 struct TimedSpan {
@@ -328,18 +334,17 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
     return true;
 }
 
-/* The pair-row fine kernel (k_score_pairs<LS, 8, W>): instantiated for these
- * (candidate-block width, slots per pair row). A half-wave that straddles two
- * lane groups reads conflict-free iff (R/2) * LS == cbx (mod 32); LS >= cbx + 65
- * holds the widest staged row (alignment column + 64-cell tile + cbx - 1). */
-struct PairShape { int cbx, ls; };
-const PairShape kPairShapes[] = { { 20, 93 }, { 32, 104 }, { 52, 125 }, { 64, 136 },
-                                  { 84, 157 }, { 96, 168 }, { 116, 189 } };
+/* The pair-row fine kernel (k_score_pairs<LS, 8, W>): LS = slots per pair row of
+ * the LDS region = alignment column + 64-cell tile + cbx - 1 candidates, even
+ * (16-byte rows for the LDS-DMA pieces). Instantiated for these LS; a candidate
+ * block may be any width cbx <= LS - 65. */
+const int kPairLS[] = { 86, 98, 118, 130, 150, 162, 182 };
 const int kPairR = 8;
 
 size_t pair_lds_bytes(int ls, int cby)
 {
-    return ((size_t)((kTile + cby) / 2 + 1) * 2 * ls + kPbMax) * 4;
+    const size_t region = (size_t)((kTile + cby) / 2 + 1) * ls * 8;
+    return ((region + 1023) / 1024) * 1024 + (size_t)kPbMax * 4;
 }
 
 bool plan_pass_pairs(int nx, int ny, PassPlan* out)
@@ -349,7 +354,8 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
             return false;
     const int R = kPairR;
     double best = -1.0;
-    for (const PairShape& sh : kPairShapes) {
+    const int max_cbx = kPairLS[sizeof(kPairLS) / sizeof(kPairLS[0]) - 1] - 65;
+    for (int ncbx = ceil_div(nx, max_cbx); ncbx <= ceil_div(nx, max_cbx) + 2; ++ncbx) {
         PassPlan p;
         p.nx = nx;
         p.ny = ny;
@@ -357,14 +363,21 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
         p.log2s = 0;
         p.pairs = true;
         p.R = R;
-        p.cbx = sh.cbx;
-        p.lstride = sh.ls;
-        p.ncbx = ceil_div(nx, sh.cbx);
-        int g = std::min(std::min(kBlock / sh.cbx, ceil_div(ny, R)), kPairMaxCby / R);
+        p.ncbx = ncbx;
+        p.cbx = ceil_div(nx, ncbx);
+        p.lstride = 0;
+        for (int ls : kPairLS)
+            if (ls >= p.cbx + 65) {
+                p.lstride = ls;
+                break;
+            }
+        if (!p.lstride)
+            continue;
+        int g = std::min(std::min(kBlock / p.cbx, ceil_div(ny, R)), kPairMaxCby / R);
         /* two workgroups per CU: at most 80 KB of LDS each */
-        while (g > 1 && pair_lds_bytes(sh.ls, g * R) > 80 * 1024)
+        while (g > 1 && pair_lds_bytes(p.lstride, g * R) > 80 * 1024)
             --g;
-        if (pair_lds_bytes(sh.ls, g * R) > 160 * 1024 - 256)
+        if (g < 1 || pair_lds_bytes(p.lstride, g * R) > 160 * 1024 - 256)
             continue;
         p.ncby = ceil_div(ny, g * R);
         g = ceil_div(ceil_div(ny, p.ncby), R);          /* balance the row blocks */
@@ -372,13 +385,19 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
         /* per (block, tile): staging grows with the region, the gather does not
          * depend on how many lanes are useful */
         const double cost = (double)p.ncbx * p.ncby *
-                            (0.04 * ((kTile + g * R) / 2 + 1) * sh.ls + 1260.0);
+                            (0.01 * ((kTile + g * R) / 2 + 1) * p.lstride + 1260.0);
         if (best < 0 || cost < best) {
             best = cost;
             *out = p;
         }
     }
     return best >= 0;
+}
+
+/* padding (cells, every side) the pair-row copy of a grid needs for a window of nx x ny candidates */
+int xgrid_pad_for(int nx, int ny)
+{
+    return (std::max(nx, ny) + kTile + kPairMaxCby + 8 + 31) & ~31;
 }
 
 /* Two LDS buffers (one barrier per tile, staging overlapped with the gather)
@@ -438,7 +457,7 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     if (p->L > 1 && !plan_pass(p->nxc, p->nyc, p->L, &p->coarse))
         return fail(ctx, CSM_EINVAL, "LowResolution %d too large for the coarse kernel", p->L);
     p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
-    p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi, kTile);
+    p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi + 1, kTile);    /* + 1: k_bin's frame shift */
     p->max_tiles = std::min(p->n, p->tiles_x * p->tiles_y) + p->n / kPbMax + 1;
     if (p->n > kMaxPoints)
         return fail(ctx, CSM_EINVAL, "more than %d beams per scan", kMaxPoints);
@@ -529,9 +548,9 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
     }
 #define PAIR_DISPATCH(CALL)                                                            \
     do {                                                                               \
-        PAIR_CASE(93, CALL) PAIR_CASE(104, CALL) PAIR_CASE(125, CALL)                  \
-        PAIR_CASE(136, CALL) PAIR_CASE(157, CALL) PAIR_CASE(168, CALL)                 \
-        PAIR_CASE(189, CALL)                                                           \
+        PAIR_CASE(86, CALL) PAIR_CASE(98, CALL) PAIR_CASE(118, CALL)                   \
+        PAIR_CASE(130, CALL) PAIR_CASE(150, CALL) PAIR_CASE(162, CALL)                 \
+        PAIR_CASE(182, CALL)                                                           \
     } while (0)
 
 #define CALL_PAIRS_SINGLE(LS, RR, WW)                                                  \
@@ -641,6 +660,13 @@ DeviceGrid* find_grid(csm_ctx* ctx, uint64_t id)
 
 void free_levels(DeviceGrid& g, bool keep_base)
 {
+    if (!keep_base) {
+        if (g.xg)
+            (void)hipFree(g.xg);
+        g.xg = nullptr;
+        g.xg_cap = 0;
+        g.xg_stale = true;
+    }
     for (size_t i = keep_base ? 1 : 0; i < g.levels.size(); ++i)
         if (g.levels[i].owned && g.levels[i].cells)
             (void)hipFree(g.levels[i].cells);
@@ -722,6 +748,37 @@ int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index)
     return CSM_OK;
 }
 
+/* The pair-row copy of level 0 with at least `need_pad` cells of zero padding. */
+int ensure_xgrid(csm_ctx* ctx, DeviceGrid& g, int need_pad)
+{
+    if (g.xg && !g.xg_stale && g.xg_pad >= need_pad)
+        return CSM_OK;
+    const int pad = std::max(need_pad, g.xg_pad);
+    const int prows = (g.rows + 2 * pad + 1) / 2 + 1;
+    const int xp = (g.cols + 2 * pad + 1) & ~1;
+    const size_t bytes = (size_t)prows * xp * 8;
+    if (bytes > g.xg_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (g.xg)
+            (void)hipFree(g.xg);
+        g.xg = nullptr;
+        g.xg_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&g.xg), bytes) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+        g.xg_cap = bytes;
+    }
+    const size_t total = (size_t)prows * xp;
+    const int blocks = (int)std::min<size_t>(4096, (total + 255) / 256);
+    ScopedTimer tm(ctx, "expand");
+    hipLaunchKernelGGL(k_expand_pairs, dim3(blocks), dim3(256), 0, ctx->stream, g.levels[0].cells, g.rows,
+                       g.cols, g.pitch, reinterpret_cast<uint2*>(g.xg), prows, xp, pad);
+    HIP_TRY(ctx, hipGetLastError());
+    g.xg_pad = pad;
+    g.xg_pitch = xp;
+    g.xg_stale = false;
+    return CSM_OK;
+}
+
 struct WindowOutputs {
     uint32_t* dump_s = nullptr;     /* device */
     uint16_t* dump_k = nullptr;
@@ -741,7 +798,9 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
                     w->coarse_level, g.levels[w->coarse_level].win, p.L);
     int rc;
     const size_t nt = p.n_theta;
-    if ((rc = ensure(ctx, ctx->sorted, nt * p.n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sorted, nt * p.n * 4 + 256))) return rc;   /* + 64 entries: the LDS-DMA of a
+                                                                             tile's list reads whole 64-entry pieces */
+    if (p.fine.pairs && (rc = ensure_xgrid(ctx, g, xgrid_pad_for(p.nx, p.ny)))) return rc;
     if ((rc = ensure(ctx, ctx->tiles, nt * p.max_tiles * sizeof(TileRec)))) return rc;
     if ((rc = ensure(ctx, ctx->ntiles, nt * 8))) return rc;
     if ((rc = ensure(ctx, ctx->misc, 256))) return rc;
@@ -809,6 +868,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.max_mult = p.fine.weighted ? kMaxMult : 1;
     bj.lstride = p.fine.lstride;
     bj.pair_mode = p.fine.pairs ? 1 : 0;
+    bj.frame_shift = p.fine.pairs ? ((p.ny - 1) & 1) : 0;
     bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
     const bool coarse_exits = w->min_known <= 1 && !force_coarse;   /* unless a beam reaches the band */
     if (p.L > 1) {
@@ -878,6 +938,9 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
 
     ScoreJob fj = base;
     fj.cells = g.levels[0].cells;
+    fj.xg = g.xg;
+    fj.xg_pitch = g.xg_pitch;
+    fj.xg_pad = g.xg_pad;
     fj.nx = p.nx;
     fj.ny = p.ny;
     fj.stride = 1;
@@ -1899,7 +1962,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         p.nx = ceil_div(2 * p.win_x + 1, big) * big;
         p.ny = ceil_div(2 * p.win_y + 1, big) * big;
         p.tiles_x = ceil_div(p.grid->cols + p.win_x + (-p.win_x + p.nx - 1), kTile);
-        p.tiles_y = ceil_div(p.grid->rows + p.win_y + (-p.win_y + p.ny - 1), kTile);
+        p.tiles_y = ceil_div(p.grid->rows + p.win_y + (-p.win_y + p.ny - 1) + 1, kTile);
         p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y) + p.n / kPbMax + 1;
         if (p.n > kMaxPoints)
             return fail(ctx, CSM_EINVAL, "query %d: more than %d beams per scan", idx[k], kMaxPoints);
@@ -1964,7 +2027,10 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     }
     if ((rc = ensure(ctx, ctx->b_prod, (resident ? 0 : scan_total * 8) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_hits, (resident ? 0 : hit_total * 8) + 64))) return rc;
-    if ((rc = ensure(ctx, ctx->b_sorted, hit_total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->b_sorted, hit_total * 4 + 256))) return rc;
+    if (lp[0].pairs)
+        for (int k = 0; k < nq; ++k)
+            if ((rc = ensure_xgrid(ctx, *pp[k].grid, xgrid_pad_for(nx, ny)))) return rc;
     if ((rc = ensure(ctx, ctx->b_sorted_rc, hit_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tile_total * sizeof(TileRec)))) return rc;
     if ((rc = ensure(ctx, ctx->b_ntiles, theta_total * 4))) return rc;
@@ -2060,6 +2126,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
         B.pair_mode = lp[0].pairs ? 1 : 0;
+        B.frame_shift = lp[0].pairs ? ((ny - 1) & 1) : 0;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {
             B.band_win[h - 1] = spec.stride[h];
@@ -2111,6 +2178,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         ScoreJob& F = sj[0][k];
         F = base;
         F.cells = g.levels[p.level[0]].cells;
+        F.xg = g.xg;
+        F.xg_pitch = g.xg_pitch;
+        F.xg_pad = g.xg_pad;
         F.nx = nx;
         F.ny = ny;
         F.stride = 1;

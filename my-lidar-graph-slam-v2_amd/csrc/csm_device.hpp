@@ -70,6 +70,8 @@ struct BinJob {
     int32_t max_mult;          /* kMaxMult: merge same-cell beams; 1: one entry per beam */
     int32_t lstride;
     int32_t pair_mode;         /* entries are aligned row pairs (pair-row fine kernel) */
+    int32_t frame_shift;       /* 0 / 1 added to the tile frame's row origin: (y_lo + y_hi + shift) even,
+                                  so that frame parity == grid-row parity of what the fine kernel reads */
     /* first row / column of the map that holds a known cell: a box that ends
      * before it is unknown on every level, so reading it as unknown is right */
     int32_t known_r0, known_c0;
@@ -93,6 +95,11 @@ struct ZeroJob {
 struct ScoreJob {
     const uint16_t* cells;     /* pitched grid level */
     int32_t rows, cols, pitch;
+    /* pair-row fine kernel: the level as expanded cells v + (v != 0) << 23 in 8-byte
+     * slots (row 2k, row 2k + 1) of one column, zero-padded by xg_pad cells on
+     * every side, xg_pitch slots per pair row (k_expand_pairs) */
+    const uint32_t* xg;
+    int32_t xg_pitch, xg_pad;
     const uint32_t* sorted_pb;
     const TileRec*  tiles;
     const int32_t*  n_tiles;

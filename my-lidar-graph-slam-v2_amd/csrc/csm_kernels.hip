@@ -87,10 +87,14 @@ __device__ __forceinline__ int cell_index(double pos, double off, double res)
  *
  * Entry words:
  *   sorted_pb, single mode: mult << 16 | (row * lstride + col)
- *   sorted_pb, pair mode:   m_odd << 20 | m_even << 16 | (pair_row * 2 * lstride + 2 * col)
+ *   sorted_pb, pair mode:   m_odd << 28 | m_even << 24 | (m_even + m_odd) << 19 |
+ *                           byte offset of the slot = (pair_row * lstride + col) * 8
  *   sorted_rc (strided levels): m_odd << 28 | m_even << 24 | row << 16 | col
  * rows / cols relative to the tile's bounding box (TileRec.r0 / c0); in pair
- * mode r0 is rounded down to an even row of the tile frame. */
+ * mode r0 is rounded down to an even row of the tile frame, and the frame is
+ * shifted by BinJob.frame_shift so that an even frame row + any candidate row
+ * offset of the fine kernel's lanes is an even GRID row (the pair-row copy of
+ * the grid pairs rows by their grid parity). */
 __device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
     extern __shared__ uint32_t sm_bin[];
@@ -141,10 +145,11 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int r_max = job.rows - 1 - job.y_lo;
     const int c_max = job.cols - 1 - job.x_lo;
     bool band = false;
+    const int fs = job.frame_shift;          /* 0 / 1: see BinJob */
     for (int i = tid; i < n; i += kBinBlock) {
         const int r = row[i], c = col[i];
-        const int rr = r + job.y_hi, cc = c + job.x_hi;
-        if (rr >= 0 && r <= r_max && cc >= 0 && c <= c_max) {
+        const int rr = r + job.y_hi + fs, cc = c + job.x_hi;
+        if (rr >= fs && r <= r_max && cc >= 0 && c <= c_max) {
             const int tile = (rr / kTile) * job.tiles_x + cc / kTile;
             const uint32_t rb = (uint32_t)(rr % kTile), cb = (uint32_t)(cc % kTile);
             atomicMin(&bb_rmin[tile], rb);
@@ -240,7 +245,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         const int rmin = pairs ? (int)(bb_rmin[i] & ~1u) : (int)bb_rmin[i];
         for (uint32_t done = 0; done < c; done += kPbMax) {
             TileRec rec;
-            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi + rmin;
+            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi - job.frame_shift + rmin;
             rec.c0 = (i % job.tiles_x) * kTile - job.x_hi + (int)bb_cmin[i];
             rec.start = off + done;
             rec.count = min(c - done, (uint32_t)kPbMax);
@@ -293,8 +298,9 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             be -= me;
             bo -= mo;
             const uint32_t pos = (me && mo) ? pos_b++ : pos_x++;
-            if (pairs)
-                out[pos] = (mo << 20) | (me << 16) | ((rb >> 1) * 2u * (uint32_t)job.lstride + 2u * cb);
+            if (pairs)      /* byte offset of the slot (8 B) | beams << 19 | m_even << 24 | m_odd << 28 */
+                out[pos] = (mo << 28) | (me << 24) | ((me + mo) << 19) |
+                           (((rb >> 1) * (uint32_t)job.lstride + cb) << 3);
             else
                 out[pos] = (me << 16) | (rb * (uint32_t)job.lstride + cb);
             if (out_rc)
@@ -793,6 +799,12 @@ __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, in
  * not know that the result arrives later: every use must sit behind lds_wait,
  * which takes the registers as in/out operands so that nothing that reads them
  * can be scheduled above the wait. */
+/* the 32-bit LDS address of a __shared__ object, for hand-written ds_* instructions */
+__device__ __forceinline__ uint32_t lds_address(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 template <int OFFSET>
 __device__ __forceinline__ void lds_read_b64(uint32_t addr, unsigned long long& q)
 {
@@ -817,29 +829,49 @@ __device__ __forceinline__ void lds_wait(unsigned long long (&q)[N])
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "n"(LATER));
 }
 
+/* Expanded, zero-padded, pair-row copy of a grid level: slot (k, c) = 8 bytes =
+ * cells (2k - pad, c - pad) and (2k + 1 - pad, c - pad) as v + (v != 0) << 23 (24
+ * bits: one v_mad_u32_u24 per gather adds value sum and known count together).
+ * The fine kernel copies windows of it into LDS with global_load_lds (no
+ * unpacking, no bounds tests, no VGPRs on the way). */
+__global__ __launch_bounds__(256) void k_expand_pairs(const uint16_t* __restrict__ cells, int rows, int cols,
+                                                     int pitch, uint2* __restrict__ xg, int xg_prows,
+                                                     int xg_pitch, int pad)
+{
+    const size_t total = (size_t)xg_prows * xg_pitch;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i / xg_pitch), c = (int)(i % xg_pitch) - pad;
+        const int r0 = 2 * k - pad;
+        uint32_t v0 = 0, v1 = 0;
+        if (c >= 0 && c < cols) {
+            if (r0 >= 0 && r0 < rows)
+                v0 = cells[(size_t)r0 * pitch + c];
+            if (r0 + 1 >= 0 && r0 + 1 < rows)
+                v1 = cells[(size_t)(r0 + 1) * pitch + c];
+        }
+        xg[i] = make_uint2(v0 + (min(v0, 1u) << 23), v1 + (min(v1, 1u) << 23));
+    }
+}
+
 /* The fine level (candidates one cell apart) with the LDS region stored in
  * ROW PAIRS: the 8-byte slot (pair row k, column c) holds the expanded cells of
- * region rows 2k and 2k + 1 at column c. A lane still owns one candidate column
- * and R (even) consecutive candidate rows, but fetches its cells with
- * ds_read_b64 -- twice the bytes per LDS cycle of ds_read_b32 -- and one entry
- * of k_bin's pair mode (an aligned row pair of one column with a beam count per
- * row) needs R/2 reads (even row only) or R/2 + 1 (odd row / both) for R or 2R
- * multiply-adds, instead of R reads per R.
+ * region rows 2k and 2k + 1 at column c. A lane owns one candidate column and R
+ * (even) consecutive candidate rows and fetches its cells with ds_read_b64 --
+ * twice the bytes per LDS cycle of ds_read_b32 -- and one entry of k_bin's pair
+ * mode (an aligned row pair of one column with a beam count per row) needs R/2
+ * reads (even row only) or R/2 + 1 (odd row / both) for R or 2R multiply-adds.
  *
- * LS = slots per pair row. A half-wave straddles two lane groups unless cbx is
- * a multiple of 32; the reads of such a half-wave stay conflict-free when
- * (R/2) * LS == cbx (mod 32) (the second group's slots continue where the
- * first group's end), which is how the host picks LS (plan_pass_pairs).
- *
- * Staging: lane pairs (2q, 2q + 1) fetch the two rows of one 2-column chunk
- * (one dword each, 256 contiguous bytes per row and wave), expand the cells to
- * v + (v != 0) << 23 and store them with two ds_write_b32 (2-way bank pattern:
- * free for stores). Entries arrive sorted by class, TileRec.pad = class counts. */
+ * Staging is LDS-DMA: the region is a window of the level's pair-row copy
+ * (k_expand_pairs: expanded and zero-padded once per map), LS slots per pair
+ * row, moved by global_load_lds_dwordx4 in 1-KiB pieces (wave-uniform LDS
+ * destination, per-lane source = piece-relative offset computed once per
+ * kernel + a scalar base per tile). No staging VALU work, no staging VGPRs.
+ * Entries arrive sorted by class, TileRec.pad = class counts. */
 template <int LS, int R, bool WEIGHTED>
 __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, int groups, int slice,
                                                  int n_slices)
 {
-    static_assert(R % 2 == 0, "pair rows");
+    static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
     const int t = blockIdx.y;
     if (t >= job.n_theta)
@@ -856,12 +888,14 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     const bool lane_on = g < groups;
     const int x0 = job.x_lo + bx * cbx;
     const int y0 = job.y_lo + by * cby;
-    constexpr int PR = 2 * LS;                          /* dwords per pair row */
-    const int max_prows = (kTile + cby) / 2 + 1;
+    constexpr int kRowBytes = LS * 8;                   /* one pair row of the region */
+    const int prows_full = (kTile + cby) / 2 + 1;
+    const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
-    uint32_t* lpb = sm_cells + max_prows * PR;
-    const int tb = lane_on ? (g * (R / 2)) * PR + 2 * dxi : 0;
+    uint32_t* lpb = sm_cells + max_pieces * 256;
+    const int tb = lane_on ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
     const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     uint32_t S[R], K[R], acc[R];
 #pragma unroll
@@ -881,114 +915,78 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         pending = 0;
     };
 
-    const int grid_rows = job.rows, grid_pitch = job.pitch;
-    const uint16_t* __restrict__ cells = job.cells;
     const int ntiles = job.in_s ? 0 : job.n_tiles[t];
     const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)t * job.n_points;
-    /* staging units (one dword = 2 cells of one row) a lane may have to fetch per tile */
-    constexpr int kMaxU = (((kTile + kPairMaxCby) / 2 + 1) * 2 * ((LS + 1) / 2) + kBlock - 1) / kBlock;
-    constexpr int kPbRegs = kPbMax / kBlock;
+    const size_t xg_row_bytes = (size_t)job.xg_pitch * 8;
+    const char* xg = reinterpret_cast<const char*>(job.xg);
+    const int pad = job.xg_pad;
 
-    uint32_t pre[kMaxU];
-    uint32_t pre_pb[kPbRegs];
-    int nch = 1, total = 0;            /* 2-column chunks per row; lane pairs' units in all */
-    int pr0 = 0, ch0 = 0, dq = 0, dr = 0;
-    TileRec rec;
-    const int half = tid >> 1, rpar = tid & 1;
-    auto fetch = [&](const TileRec& tr) {
-        const int cs = (tr.c0 + x0) & ~1;                /* dword aligned first column */
-        const int a = (tr.c0 + x0) - cs;                 /* 0..1 */
-        const int nprows = (tr.h + cby) >> 1;            /* rows 0 .. h + cby - 2, rounded up to pairs */
-        nch = (a + tr.w + (cbx - 1) + 1) >> 1;
-        total = nprows * nch;
-        const int gr0 = tr.r0 + y0;
-        /* unit q = half + k * (kBlock / 2) -> (pair row, chunk), stepped without a division */
-        pr0 = half / nch;
-        ch0 = half - pr0 * nch;
-        dq = (kBlock / 2) / nch;
-        dr = (kBlock / 2) - dq * nch;
-        int pr = pr0, ch = ch0;
+    /* piece pc = wave + 8 k of the region (LDS bytes [1024 pc, 1024 pc + 1024)): this
+     * lane's 16 bytes sit in pair row prow at byte cb of it */
+    constexpr int kMaxP = ((((kTile + kPairMaxCby) / 2 + 1) * kRowBytes + 1023) / 1024 + 7) / 8;
+    uint32_t goff[kMaxP];
 #pragma unroll
-        for (int k = 0; k < kMaxU; ++k) {
-            const int q = half + k * (kBlock / 2);
-            const int gr = gr0 + 2 * pr + rpar, gc = cs + 2 * ch;
-            const bool ok = q < total && gr >= 0 && gr < grid_rows && gc >= 0 && gc < grid_pitch;
-            uint32_t v = 0;
-            if (ok)
-                v = *reinterpret_cast<const uint32_t*>(cells + (size_t)gr * grid_pitch + gc);
-            pre[k] = v;
-            pr += dq;
-            ch += dr;
-            if (ch >= nch) {
-                ch -= nch;
-                ++pr;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kPbRegs; ++q) {
-            const uint32_t bi = tid + q * kBlock;
-            pre_pb[q] = bi < tr.count ? pbs[tr.start + bi] : 0u;
-        }
-    };
-    auto expand = [](uint32_t v) { return v + (min(v, 1u) << 23); };
-
-    int ti = slice;
-    if (ti < ntiles) {
-        rec = recs[ti];
-        fetch(rec);
+    for (int k = 0; k < kMaxP; ++k) {
+        const uint32_t ob = (uint32_t)(wave + 8 * k) * 1024u + (uint32_t)lane * 16u;
+        const uint32_t prow = ob / (uint32_t)kRowBytes, cb = ob - prow * (uint32_t)kRowBytes;
+        goff[k] = prow * (uint32_t)xg_row_bytes + cb;
     }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    TileRec rec;
+    int ti = slice;
+    if (ti < ntiles)
+        rec = recs[ti];
     for (; ti < ntiles; ti += n_slices) {
-        __syncthreads();                                 /* previous tile consumed */
-        {
-            int pr = pr0, ch = ch0;
-#pragma unroll
-            for (int k = 0; k < kMaxU; ++k) {
-                if (half + k * (kBlock / 2) < total) {
-                    const uint32_t w = pre[k];
-                    uint32_t* dst = sm_cells + pr * PR + 4 * ch + rpar;
-                    dst[0] = expand(w & 0xffffu);
-                    dst[2] = expand(w >> 16);
-                }
-                pr += dq;
-                ch += dr;
-                if (ch >= nch) {
-                    ch -= nch;
-                    ++pr;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kPbRegs; ++q)
-            lpb[tid + q * kBlock] = pre_pb[q];
-        __syncthreads();
         /* wave-uniform values, told to the compiler as such: the entry loops then run
          * on scalar registers and scalar branches */
-        const int a = __builtin_amdgcn_readfirstlane((rec.c0 + x0) & 1);
+        const int c00 = __builtin_amdgcn_readfirstlane(rec.c0) + x0;
+        const int gr0 = __builtin_amdgcn_readfirstlane(rec.r0) + y0;          /* even */
+        const int a = c00 & 1;
         const int cnt = __builtin_amdgcn_readfirstlane((int)rec.count);
+        const int start = __builtin_amdgcn_readfirstlane((int)rec.start);
+        const int nprows = (__builtin_amdgcn_readfirstlane(rec.h) + cby) >> 1;
         const int end_both = __builtin_amdgcn_readfirstlane(rec.pad[0]);
         const int end_even = end_both + __builtin_amdgcn_readfirstlane(rec.pad[1]);
-        if (ti + n_slices < ntiles) {
+        const int npieces = (nprows * kRowBytes + 1023) >> 10;
+        const char* src = xg + ((size_t)((gr0 + pad) >> 1) * job.xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
+        if (ti + n_slices < ntiles)
             rec = recs[ti + n_slices];
-            fetch(rec);
+        __syncthreads();                                 /* previous tile consumed */
+#pragma unroll
+        for (int k = 0; k < kMaxP; ++k) {
+            const int pc = wave + 8 * k;
+            if (pc < npieces)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(src + goff[k]), (lds_ptr)(sm_cells + pc * 256), 16, 0, 0);
         }
-        /* One entry: `pbv` = m_odd << 20 | m_even << 16 | dword offset of its first slot.
-         * CLS 0: both rows hit, 1: even row only, 2: odd row only. The reads are
-         * hand-issued ds_read_b64 (the compiler would fuse two of them into a
-         * ds_read2_b64, which runs at half the rate) and software-pipelined: the
-         * next entry's reads are in flight while this entry's multiply-adds run. */
-        const uint32_t lane_addr = (uint32_t)(tb + 2 * a) * 4u;      /* byte address of the lane's slot */
+#pragma unroll
+        for (int e = 0; e < kPbMax / 64 / 8; ++e) {
+            const int pe = wave + 8 * e;
+            if (pe * 64 < cnt)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(pbs + start + pe * 64 + lane),
+                                                 (lds_ptr)(lpb + pe * 64), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        /* One entry: `pbv` = m_odd << 28 | m_even << 24 | beams << 19 | byte offset of its
+         * first slot. CLS 0: both rows hit, 1: even row only, 2: odd row only. The reads
+         * are hand-issued ds_read_b64 (the compiler would fuse two of them into a
+         * ds_read2_b64, which runs at half the rate). */
+        const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
         auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
             constexpr int CLS = decltype(cls)::value;
-            const uint32_t addr = lane_addr + ((pbv & 0xffffu) << 2);
-            lds_read_b64<0 * LS * 8>(addr, q[0]);
-            lds_read_b64<1 * LS * 8>(addr, q[1]);
+            const uint32_t addr = lane_addr + (pbv & 0x7ffffu);
+            lds_read_b64<0 * kRowBytes>(addr, q[0]);
+            lds_read_b64<1 * kRowBytes>(addr, q[1]);
             if (R >= 6)
-                lds_read_b64<2 * LS * 8>(addr, q[2]);
+                lds_read_b64<2 * kRowBytes>(addr, q[2]);
             if (R >= 8)
-                lds_read_b64<3 * LS * 8>(addr, q[3]);
+                lds_read_b64<3 * kRowBytes>(addr, q[3]);
             if (CLS != 1)
-                lds_read_b64<(R / 2) * LS * 8>(addr, q[R / 2]);
+                lds_read_b64<(R / 2) * kRowBytes>(addr, q[R / 2]);
         };
         auto mads = [&](uint32_t pbv, auto cls, const unsigned long long (&q)[R / 2 + 1]) {
             constexpr int CLS = decltype(cls)::value;
@@ -998,11 +996,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
                 v[2 * i] = (uint32_t)q[i];
                 v[2 * i + 1] = (uint32_t)(q[i] >> 32);
             }
-            const uint32_t me = (pbv >> 16) & 15u, mo = pbv >> 20;
-            const int mm = (int)(me + mo);
-            if (pending + mm > 128)
-                flush();
-            pending += mm;
+            const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
             if (WEIGHTED) {
                 /* the two multiply-adds of one accumulator are kept R instructions
                  * apart: back to back the compiler pads them with s_nop */
@@ -1026,35 +1020,54 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
                 }
             }
         };
-        /* entries [j, end) of one class; 64 entries per LDS read, broadcast with v_readlane */
+        auto beams_of = [&](uint32_t pbv) { return (int)((pbv >> 19) & 31u); };
+        /* Entries [j, end) of one class; 64 entries per LDS read of the list,
+         * broadcast with v_readlane. Four entries per group, straight-line: a
+         * hand-issued read must reach its lds_wait without crossing a loop edge
+         * (a register copy the compiler places on an edge would copy the
+         * register before the data has landed), so the pipeline drains at the
+         * end of every group. */
         int j = 0;
         uint32_t pb_cur = lpb[lane];
         auto run = [&](int end, auto cls) {
             constexpr int CLS = decltype(cls)::value;
             constexpr int NP = CLS == 1 ? R / 2 : R / 2 + 1;     /* reads per entry */
+            constexpr int NQ = R / 2 + 1;
             while (j < end) {
                 const int stop = min(end, (j | 63) + 1);
-                unsigned long long qa[R / 2 + 1], qb[R / 2 + 1];
-                uint32_t oa = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63), ob = 0;
-                issue(oa, cls, qa);
-                for (; j + 2 <= stop; j += 2) {
-                    ob = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
-                    issue(ob, cls, qb);
-                    lds_wait<NP, R / 2 + 1>(qa);              /* all but the NP reads just issued */
-                    mads(oa, cls, qa);
-                    if (j + 2 < stop) {
-                        oa = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
-                        issue(oa, cls, qa);
-                        lds_wait<NP, R / 2 + 1>(qb);
-                    } else {
-                        lds_wait<0, R / 2 + 1>(qb);
-                    }
-                    mads(ob, cls, qb);
+                for (; j + 4 <= stop; j += 4) {
+                    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+                    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
+                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
+                    const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
+                    const int mm = beams_of(o0) + beams_of(o1) + beams_of(o2) + beams_of(o3);
+                    if (pending + mm > 128)
+                        flush();
+                    pending += mm;
+                    unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ];
+                    issue(o0, cls, qa);
+                    issue(o1, cls, qb);
+                    lds_wait<NP, NQ>(qa);                 /* all but the NP reads just issued */
+                    mads(o0, cls, qa);
+                    issue(o2, cls, qc);
+                    lds_wait<NP, NQ>(qb);
+                    mads(o1, cls, qb);
+                    issue(o3, cls, qd);
+                    lds_wait<NP, NQ>(qc);
+                    mads(o2, cls, qc);
+                    lds_wait<0, NQ>(qd);
+                    mads(o3, cls, qd);
                 }
-                if (j < stop) {
-                    lds_wait<0, R / 2 + 1>(qa);
-                    mads(oa, cls, qa);
-                    ++j;
+                for (; j < stop; ++j) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+                    const int mm = beams_of(o);
+                    if (pending + mm > 128)
+                        flush();
+                    pending += mm;
+                    unsigned long long qa[NQ];
+                    issue(o, cls, qa);
+                    lds_wait<0, NQ>(qa);
+                    mads(o, cls, qa);
                 }
                 if ((j & 63) == 0 && j < cnt)
                     pb_cur = lpb[j + lane];

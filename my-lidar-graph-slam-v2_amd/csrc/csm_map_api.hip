@@ -387,6 +387,7 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
         else
             g.levels[i].cells = g.levels[0].cells;     /* an alias of the base (window 1) */
     }
+    g.xg_stale = true;         /* the pair-row copy follows the base */
     g.rows = rows;
     g.cols = cols;
     g.pitch = pitch;

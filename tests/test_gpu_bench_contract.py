@@ -61,7 +61,8 @@ def test_default_line():
     assert c3["leaves_per_step"] == 256 * 59 * 52 * 52 and c3["found"] > 0
     _check_roofline(c3["roofline"])
     c5 = cf["config5"]
-    assert c5["candidates"] == 1441 * 804 * 804 and c5["value"] > 1e8 and c5["found"] == 1
+    assert c5["candidates"] % (804 * 804) == 0 and c5["candidates"] > 9.2e8
+    assert c5["value"] > 1e8 and c5["found"] == 1
     _check_roofline(c5["roofline"])
 
 
