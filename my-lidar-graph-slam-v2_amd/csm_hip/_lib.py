@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcsm_hip.so")
+# CSM_HIP_LIB: a tuning build of the same library (tools/build_variant.sh), for A/B runs on one box
+LIB_PATH = os.environ.get("CSM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libcsm_hip.so")
 
 CSM_OK = 0
 CSM_ENOENT = -2

@@ -391,7 +391,14 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
             *out = p;
         }
     }
-    return best >= 0;
+    if (best < 0)
+        return false;
+    if (const char* e = getenv("CSM_PAIR_LS")) {        /* tuning: force the row pitch */
+        const int ls = atoi(e);
+        if (ls >= out->cbx + 65 && ls % 2 == 0)
+            out->lstride = ls;
+    }
+    return true;
 }
 
 /* padding (cells, every side) the pair-row copy of a grid needs for a window of nx x ny candidates */
@@ -499,6 +506,13 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         }                                                                              \
         launched = true;                                                               \
     }
+#ifdef CSM_FAST_BUILD
+/* tuning builds (tools/build_variant.sh): only the instantiations bench.py's configs[1] uses */
+#define SCORE_DISPATCH(CALL)                                                           \
+    do {                                                                               \
+        SCORE_CASE(160, 7, 0, CALL) SCORE_CASE(192, 1, 1, CALL)                        \
+    } while (0)
+#else
 #define SCORE_DISPATCH(CALL)                                                           \
     do {                                                                               \
         SCORE_CASE(96, 4, 0, CALL) SCORE_CASE(96, 5, 0, CALL)                          \
@@ -518,6 +532,7 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         SCORE_CASE(128, 4, 2, CALL) SCORE_CASE(192, 1, 2, CALL)                        \
         SCORE_CASE(192, 2, 2, CALL) SCORE_CASE(192, 4, 2, CALL)                        \
     } while (0)
+#endif
 
 #define CALL_SINGLE(LS, RR, ST, WW)                                                    \
     do {                                                                               \
@@ -546,12 +561,19 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         }                                                                              \
         launched = true;                                                               \
     }
+#ifdef CSM_FAST_BUILD
+#define PAIR_DISPATCH(CALL)                                                            \
+    do {                                                                               \
+        PAIR_CASE(150, CALL)                                                           \
+    } while (0)
+#else
 #define PAIR_DISPATCH(CALL)                                                            \
     do {                                                                               \
         PAIR_CASE(86, CALL) PAIR_CASE(98, CALL) PAIR_CASE(118, CALL)                   \
         PAIR_CASE(130, CALL) PAIR_CASE(150, CALL) PAIR_CASE(162, CALL)                 \
         PAIR_CASE(182, CALL)                                                           \
     } while (0)
+#endif
 
 #define CALL_PAIRS_SINGLE(LS, RR, WW)                                                  \
     do {                                                                               \
@@ -613,10 +635,14 @@ int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n
         pp.lstride = 128;
     const dim3 grid(pp.ncb(), n_theta, 1);
     bool launched = false;
+#ifdef CSM_FAST_BUILD
+    ARGMAX_CASE(128, 8) ARGMAX_CASE(160, 7)
+#else
     ARGMAX_CASE(96, 4) ARGMAX_CASE(96, 5) ARGMAX_CASE(96, 6) ARGMAX_CASE(96, 7) ARGMAX_CASE(96, 8)
     ARGMAX_CASE(128, 4) ARGMAX_CASE(128, 5) ARGMAX_CASE(128, 6) ARGMAX_CASE(128, 7) ARGMAX_CASE(128, 8)
     ARGMAX_CASE(160, 4) ARGMAX_CASE(160, 5) ARGMAX_CASE(160, 6) ARGMAX_CASE(160, 7) ARGMAX_CASE(160, 8)
     ARGMAX_CASE(192, 4) ARGMAX_CASE(192, 5) ARGMAX_CASE(192, 6) ARGMAX_CASE(192, 7) ARGMAX_CASE(192, 8)
+#endif
     if (!launched)
         return fail(ctx, CSM_EINVAL, "internal: no arg-max kernel for lstride %d R %d", pp.lstride, pp.R);
     HIP_TRY(ctx, hipGetLastError());
@@ -931,8 +957,10 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         (void)nodes;
         ScopedTimer tm(ctx, "score_coarse");
         /* few candidates per slice: split the tile list over blockIdx.z so
-         * enough workgroups are in flight to hide the staging latency */
-        if ((rc = launch_score(ctx, cj, p.coarse, p.n_theta, kCoarseSlices)))
+         * enough workgroups are in flight to hide the staging latency -- unless
+         * the pass only runs when a beam reaches the edge band (rare): then one
+         * slice, so that the launch that normally exits at once stays small */
+        if ((rc = launch_score(ctx, cj, p.coarse, p.n_theta, coarse_exits ? 1 : kCoarseSlices)))
             return rc;
     }
 
@@ -2270,8 +2298,13 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         /* keep >= ~2k workgroups in flight: split the tile list when the
          * level has few candidate blocks */
         const long blocks = (long)lp[h].ncb() * n_theta_max * nq;
-        const int n_slices =
-            blocks >= 2048 ? 1 : (int)std::min<long>(8, ceil_div(2048, (int)std::max<long>(1, blocks)));
+        /* a level that only runs when a beam reaches the edge band (rare) is launched
+         * unsplit: the launch that normally exits at once stays small */
+        bool all_exit = true;
+        for (int k = 0; k < nq; ++k)
+            all_exit = all_exit && sj[h][k].skip_unless_band;
+        const int n_slices = (blocks >= 2048 || all_exit)
+                                 ? 1 : (int)std::min<long>(8, ceil_div(2048, (int)std::max<long>(1, blocks)));
         ScopedTimer tm(ctx, "score_coarse");
         if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[h]), nq, lp[h],
                                      n_theta_max, n_slices)))

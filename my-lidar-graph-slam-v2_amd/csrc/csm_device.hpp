@@ -32,6 +32,8 @@ struct TileRec {
                             (the rest: "odd row only"); single mode: 0, count */
 };
 
+static_assert(sizeof(TileRec) == 32, "copied into LDS as two uint4");
+
 /* Best candidate of one workgroup (or of a reduction of several). */
 struct BlockBest {
     unsigned long long key;    /* 0 = no eligible candidate */
@@ -100,6 +102,7 @@ struct ScoreJob {
      * every side, xg_pitch slots per pair row (k_expand_pairs) */
     const uint32_t* xg;
     int32_t xg_pitch, xg_pad;
+    int32_t pad0;
     const uint32_t* sorted_pb;
     const TileRec*  tiles;
     const int32_t*  n_tiles;

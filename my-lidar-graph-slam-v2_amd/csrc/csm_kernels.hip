@@ -152,10 +152,6 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         if (rr >= fs && r <= r_max && cc >= 0 && c <= c_max) {
             const int tile = (rr / kTile) * job.tiles_x + cc / kTile;
             const uint32_t rb = (uint32_t)(rr % kTile), cb = (uint32_t)(cc % kTile);
-            atomicMin(&bb_rmin[tile], rb);
-            atomicMax(&bb_rmax[tile], rb);
-            atomicMin(&bb_cmin[tile], cb);
-            atomicMax(&bb_cmax[tile], cb);
             const uint32_t rkey = pairs ? rb >> 1 : rb;
             const uint32_t key = (((uint32_t)tile << 12) | (rkey << 6) | cb) + 1u;
             uint32_t slot = (key * 2654435761u) >> 12 & hmask;
@@ -191,6 +187,18 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         const uint32_t ce = chunks(hval[sl] & 0xffffu), co = chunks(hval[sl] >> 16);
         const uint32_t both = min(ce, co);
         const int tile = (int)((key - 1u) >> 12);
+        /* the tile's bounding box, from the distinct cells (here the lanes of a wave hit
+         * different tiles; in pass A neighbouring beams share a tile and the same-address
+         * LDS atomics of a whole wave serialised: 190 us per 64-window launch) */
+        {
+            const uint32_t rk = ((key - 1u) >> 6) & 63u, cbk = (key - 1u) & 63u;
+            const uint32_t rlo = pairs ? 2u * rk + (ce ? 0u : 1u) : rk;
+            const uint32_t rhi = pairs ? 2u * rk + (co ? 1u : 0u) : rk;
+            atomicMin(&bb_rmin[tile], rlo);
+            atomicMax(&bb_rmax[tile], rhi);
+            atomicMin(&bb_cmin[tile], cbk);
+            atomicMax(&bb_cmax[tile], cbk);
+        }
         atomicAdd(&hist[tile], max(ce, co));
         if (both)
             atomicAdd(&n_both[tile], both);
@@ -918,7 +926,10 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     const int ntiles = job.in_s ? 0 : job.n_tiles[t];
     const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)t * job.n_points;
-    const size_t xg_row_bytes = (size_t)job.xg_pitch * 8;
+    /* every job field the tile loop needs, read once: `job` lives in global memory and
+     * a read inside the loop is a load per tile (a stray one cost 7 % of the kernel) */
+    const size_t xg_pitch = (size_t)job.xg_pitch;
+    const size_t xg_row_bytes = xg_pitch * 8;
     const char* xg = reinterpret_cast<const char*>(job.xg);
     const int pad = job.xg_pad;
 
@@ -951,7 +962,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         const int end_both = __builtin_amdgcn_readfirstlane(rec.pad[0]);
         const int end_even = end_both + __builtin_amdgcn_readfirstlane(rec.pad[1]);
         const int npieces = (nprows * kRowBytes + 1023) >> 10;
-        const char* src = xg + ((size_t)((gr0 + pad) >> 1) * job.xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
+        const char* src = xg + ((size_t)((gr0 + pad) >> 1) * xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
         if (ti + n_slices < ntiles)
             rec = recs[ti + n_slices];
         __syncthreads();                                 /* previous tile consumed */
