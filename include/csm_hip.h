@@ -312,6 +312,60 @@ int  csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
  * (the concatenation of src/mapping/loop_detector_fpga_parallel.cpp:53-56). */
 int  csm_copy_last_batch_records(csm_ctx* ctx, csm_result* dst_dev);
 
+/* ---- several GPUs behind one detector object, in one process ----
+ * The reference's precedent is LoopDetectorFPGAParallel
+ * (src/mapping/loop_detector_fpga_parallel.cpp:42-56): Detect() cuts the query
+ * vector into contiguous halves, runs one std::thread per FPGA core and
+ * concatenates the per-core results. A csm_group owns one csm_ctx per listed
+ * device; its batch calls cut the queries into contiguous blocks
+ * (csm_shard_bounds), run one host thread per member on its block and finish
+ * with ONE exchange of the 48-byte best records (csm_allgather_results). */
+typedef struct csm_group csm_group;
+
+/* Block [*lo, *hi) of `member`: sizes differ by at most one, earlier members
+ * take the larger blocks (n_members = 2: the first half / second half split of
+ * loop_detector_fpga_parallel.cpp:42-46). Pure host arithmetic. */
+void csm_shard_bounds(int32_t n_queries, int32_t member, int32_t n_members,
+                      int32_t* lo, int32_t* hi);
+/* One context per entry of device_ids (CSM_ENODEV if one cannot be opened,
+ * like LoadBitstream's failure, src/slam_launcher.cpp:83-107). Listing a
+ * device twice gives two members on it (two streams): meant for tests on a
+ * one-GPU box. */
+int  csm_group_create(const int32_t* device_ids, int32_t n_devices, csm_group** out);
+int  csm_group_destroy(csm_group* group);
+int32_t csm_group_size(const csm_group* group);
+/* The member's context: upload / release the maps of the queries its block will
+ * hold through it (csm_upload_grid, csm_has_grid, ...). Owned by the group. */
+csm_ctx* csm_group_member(csm_group* group, int32_t member);
+const char* csm_group_last_error(const csm_group* group);
+
+/* csm_bnb_match_batch / csm_correlative_match_batch over the group: queries
+ * [lo_k, hi_k) go to member k, whose context must hold their maps; out[i] <->
+ * queries[i]. Ends with csm_allgather_results; out[i].raw is the record that
+ * came back through the exchange. */
+int  csm_group_bnb_match_batch(csm_group* group, const csm_loop_query* queries, int32_t n_queries,
+                               const csm_bnb_params* params, csm_summary* out);
+int  csm_group_correlative_match_batch(csm_group* group, const csm_loop_query* queries,
+                                       int32_t n_queries, const csm_correlative_params* params,
+                                       csm_summary* out);
+/* The exchange step of the last group batch (where the reference concatenates
+ * two vectors, src/mapping/loop_detector_fpga_parallel.cpp:53-56): every
+ * member's block of device-resident records, padded to the largest block, is
+ * all-gathered so that EVERY member's device buffer holds all records.
+ * Members on distinct devices: ncclAllGather (RCCL over xGMI; librccl is
+ * loaded on first use). One member, or members sharing a device: copies
+ * through the host. host_out (may be null) receives the n_queries records in
+ * query order, read back from member 0's gathered buffer. */
+int  csm_allgather_results(csm_group* group, csm_result* host_out);
+/* Member `member`'s gathered device buffer after csm_allgather_results:
+ * n_members blocks of *block records each (block k = member k's queries, the
+ * tail of a shorter block zero). Valid until the next group batch. */
+int  csm_group_gathered_records_dev(csm_group* group, int32_t member,
+                                    const csm_result** dev, int32_t* block);
+/* used_rccl: 1 if the exchange runs over RCCL; last_gather_us: host wall time
+ * of the last csm_allgather_results. */
+int  csm_group_exchange_info(const csm_group* group, int32_t* used_rccl, double* last_gather_us);
+
 /* ScanMatcherGridSearch constructor arguments + thresholds
  * (inc/mapping/scan_matcher_grid_search.hpp, src/scan_matcher_factory.cpp) */
 typedef struct {

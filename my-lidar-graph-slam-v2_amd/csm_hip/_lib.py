@@ -170,6 +170,18 @@ SIGNATURES = {
     "csm_host_map_resize": (C.c_int, [_P(MapShape), C.c_void_p, C.c_int32, C.c_void_p]),
     "csm_update_map_with_scan": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
                                            _P(MapBuilderParams), _P(MapBuildInfo)]),
+    "csm_shard_bounds": (None, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    "csm_group_create": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p)]),
+    "csm_group_destroy": (C.c_int, [C.c_void_p]),
+    "csm_group_size": (C.c_int32, [C.c_void_p]),
+    "csm_group_member": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "csm_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "csm_group_bnb_match_batch": (C.c_int, [C.c_void_p, _P(LoopQuery), C.c_int32, _P(BnbParams), _P(Summary)]),
+    "csm_group_correlative_match_batch": (C.c_int, [C.c_void_p, _P(LoopQuery), C.c_int32,
+                                                    _P(CorrelativeParams), _P(Summary)]),
+    "csm_allgather_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "csm_group_gathered_records_dev": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_int32)]),
+    "csm_group_exchange_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_double)]),
     "csm_enable_kernel_timing": (C.c_int, [_ctx, C.c_int32]),
     "csm_kernel_time": (C.c_int, [_ctx, C.c_char_p, _P(C.c_double), _P(C.c_int64)]),
     "csm_reset_kernel_timing": (C.c_int, [_ctx]),

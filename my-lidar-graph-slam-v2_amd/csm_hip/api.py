@@ -440,6 +440,92 @@ class Context:
         return ms.value, n.value
 
 
+def host_shard_bounds(n_queries, member, n_members):
+    lo, hi = C.c_int32(), C.c_int32()
+    L.load().csm_shard_bounds(n_queries, member, n_members, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class Group:
+    """csm_group: one context per listed device inside this process; batches are cut
+    into contiguous blocks, one host thread per member, one all-gather of the
+    records (RCCL when the devices differ)."""
+
+    def __init__(self, device_ids):
+        self.lib = L.load()
+        self._g = C.c_void_p()
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        rc = self.lib.csm_group_create(_ptr(ids), ids.size, C.byref(self._g))
+        if rc:
+            self._g = C.c_void_p()
+            raise CsmError(rc, "csm_group_create failed")
+        self.members = []
+        for k in range(self.lib.csm_group_size(self._g)):
+            ctx = Context.__new__(Context)          # a view of the member: the group owns it
+            ctx.lib, ctx.shapes = self.lib, {}
+            ctx._ctx = C.c_void_p(self.lib.csm_group_member(self._g, k))
+            ctx.close = lambda: None
+            self.members.append(ctx)
+
+    def close(self):
+        if self._g:
+            for m in self.members:
+                m._ctx = C.c_void_p()
+            self.lib.csm_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise CsmError(rc, self.lib.csm_group_last_error(self._g).decode())
+
+    def upload_grids(self, queries, grids):
+        """Every query's map to the member whose block holds the query."""
+        n, m = len(queries), len(self.members)
+        for k, ctx in enumerate(self.members):
+            lo, hi = host_shard_bounds(n, k, m)
+            for q in queries[lo:hi]:
+                if not ctx.has_grid(q["map_id"]):
+                    ctx.upload_grid(q["map_id"], grids[q["map_id"]])
+
+    def bnb_match_batch(self, queries, range_x, range_y, range_theta, node_height_max,
+                        score_threshold, known_rate_threshold, as_records=False):
+        prep = self.members[0].prepare_queries(queries)
+        p = L.BnbParams()
+        p.range_x, p.range_y, p.range_theta = range_x, range_y, range_theta
+        p.node_height_max = node_height_max
+        p.score_threshold, p.known_rate_threshold = score_threshold, known_rate_threshold
+        out = (L.Summary * prep.n)()
+        self._check(self.lib.csm_group_bnb_match_batch(self._g, prep.arr, prep.n, C.byref(p), out))
+        return SummaryArray(out) if as_records else [summary_to_dict(o) for o in out]
+
+    def gathered_records(self, member):
+        """Member `member`'s device buffer after the exchange, read back: uint8 [n_members, block, 48]."""
+        dev, block = C.c_void_p(), C.c_int32()
+        self._check(self.lib.csm_group_gathered_records_dev(self._g, member, C.byref(dev), C.byref(block)))
+        m = len(self.members)
+        n_bytes = m * block.value * C.sizeof(L.Result)
+        out = np.zeros(n_bytes, np.uint8)
+        self.members[member].synchronize()
+        # a plain device-to-host copy of a raw pointer
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), dev, ctypes.c_size_t(n_bytes), 2)
+        if rc:
+            raise CsmError(rc, "hipMemcpy failed")
+        return out.reshape(m, block.value, C.sizeof(L.Result))
+
+    def exchange_info(self):
+        used, us = C.c_int32(), C.c_double()
+        self._check(self.lib.csm_group_exchange_info(self._g, C.byref(used), C.byref(us)))
+        return bool(used.value), us.value
+
+
 class ScanMatcherCorrelativeHIP:
     """Drop-in for ScanMatcherCorrelative (constructor arguments as in
     src/my_lidar_graph_slam/scan_matcher_factory.cpp:173-177)."""

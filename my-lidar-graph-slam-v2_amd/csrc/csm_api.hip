@@ -2871,3 +2871,5 @@ int csm_reset_kernel_timing(csm_ctx* ctx)
 }
 
 } /* extern "C" */
+
+#include "csm_group.hip"

@@ -13,6 +13,7 @@
  */
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -165,7 +166,20 @@ int main(int argc, char** argv)
                     r.mEstimatedPose.mTheta, r.mScoreValue, r.mWinSizeX, r.mWinSizeY, r.mWinSizeTheta);
         return 0;
     }
-    auto d = mode == 1 ? LoopDetectorBranchBoundHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7])
+    /* CSM_DEMO_DEVICES="0,0": the detector over a device list (here two members on GPU 0) */
+    std::vector<int> devices;
+    if (const char* e = std::getenv("CSM_DEMO_DEVICES"))
+        for (const char* p = e; *p;) {
+            devices.push_back(std::atoi(p));
+            while (*p && *p != ',')
+                ++p;
+            if (*p == ',')
+                ++p;
+        }
+    if (devices.empty())
+        devices.push_back(0);
+    auto d = mode == 1 ? LoopDetectorBranchBoundHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7],
+                                                            devices)
                        : nullptr;
     auto dc = mode == 2 ? LoopDetectorCorrelativeHIP::Create("demo", pi, prm[3], prm[4], prm[5], prm[6], prm[7])
                         : nullptr;

@@ -371,23 +371,41 @@ public:
     /* scoreThreshold / knownRateThreshold as LoopDetectorBranchBound
      * (src/mapping/loop_detector_branch_bound.cpp:38-56); nodeHeightMax and the
      * search ranges as its ScanMatcherBranchBound
-     * (src/scan_matcher_factory.cpp:22-26). */
+     * (src/scan_matcher_factory.cpp:22-26). deviceIds: the GPUs the detector
+     * spreads a Detect() call over -- contiguous blocks of the query vector, one
+     * host thread per GPU inside the library, as LoopDetectorFPGAParallel does
+     * with its two FPGA cores (src/mapping/loop_detector_fpga_parallel.cpp:42-56). */
+    static std::unique_ptr<LoopDetectorBranchBoundHIP> Create(
+        const std::string& loopDetectorName, int nodeHeightMax, double rangeX, double rangeY,
+        double rangeTheta, double scoreThreshold, double knownRateThreshold,
+        const std::vector<int>& deviceIds)
+    {
+        if (!(scoreThreshold > 0.0 && scoreThreshold <= 1.0) ||
+            !(knownRateThreshold > 0.0 && knownRateThreshold <= 1.0) || deviceIds.empty())
+            return nullptr;
+        std::vector<std::int32_t> ids(deviceIds.begin(), deviceIds.end());
+        csm_group* group = nullptr;
+        if (csm_group_create(ids.data(), static_cast<std::int32_t>(ids.size()), &group) != 0)
+            return nullptr;
+        return std::unique_ptr<LoopDetectorBranchBoundHIP>(new LoopDetectorBranchBoundHIP(
+            loopDetectorName, nodeHeightMax, rangeX, rangeY, rangeTheta, scoreThreshold,
+            knownRateThreshold, group));
+    }
+
     static std::unique_ptr<LoopDetectorBranchBoundHIP> Create(
         const std::string& loopDetectorName, int nodeHeightMax, double rangeX, double rangeY,
         double rangeTheta, double scoreThreshold, double knownRateThreshold, int deviceId = 0)
     {
-        if (!(scoreThreshold > 0.0 && scoreThreshold <= 1.0) ||
-            !(knownRateThreshold > 0.0 && knownRateThreshold <= 1.0))
-            return nullptr;
-        detail::CtxPtr ctx = detail::MakeContext(deviceId);
-        if (!ctx)
-            return nullptr;
-        return std::unique_ptr<LoopDetectorBranchBoundHIP>(new LoopDetectorBranchBoundHIP(
-            loopDetectorName, nodeHeightMax, rangeX, rangeY, rangeTheta, scoreThreshold,
-            knownRateThreshold, std::move(ctx)));
+        return Create(loopDetectorName, nodeHeightMax, rangeX, rangeY, rangeTheta, scoreThreshold,
+                      knownRateThreshold, std::vector<int> { deviceId });
     }
 
+    ~LoopDetectorBranchBoundHIP() { csm_group_destroy(this->mGroup); }
+    LoopDetectorBranchBoundHIP(const LoopDetectorBranchBoundHIP&) = delete;
+    LoopDetectorBranchBoundHIP& operator=(const LoopDetectorBranchBoundHIP&) = delete;
+
     const std::string& Name() const { return this->mName; }
+    int NumOfDevices() const { return csm_group_size(this->mGroup); }
 
     /* LoopDetector::Detect: results only for the queries where a pose was
      * found, in query order (loop_detector_branch_bound.cpp:107-135). */
@@ -396,25 +414,37 @@ public:
         LoopDetectionResultVector results;
         if (queries.empty())
             return results;
-        csm_ctx* ctx = this->mCtx.get();
+        const std::int32_t n = static_cast<std::int32_t>(queries.size());
+        const std::int32_t members = csm_group_size(this->mGroup);
         std::vector<csm_loop_query> flat(queries.size());
-        for (std::size_t i = 0; i < queries.size(); ++i) {
-            const LoopDetectionQuery& q = queries[i];
-            const GridMapView& g = q.mReferenceLocalMap;
-            /* finished local maps are immutable: upload once per id
-             * (mPrecompMaps, loop_detector_branch_bound.hpp:98) */
-            if (!csm_has_grid(ctx, g.mId))
-                CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, g.mId, g.mValues, g.mRows, g.mCols));
-            csm_loop_query& f = flat[i];
-            f.map_id = g.mId;
-            f.geometry = { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
-            f.scan = detail::ToScan(q.mQueryScanData);
-            const double start[3] = { q.mReferenceLocalMapNodeGlobalPose.mX,
-                                      q.mReferenceLocalMapNodeGlobalPose.mY,
-                                      q.mReferenceLocalMapNodeGlobalPose.mTheta };
-            const double end[3] = { q.mQueryScanNodeGlobalPose.mX, q.mQueryScanNodeGlobalPose.mY,
-                                    q.mQueryScanNodeGlobalPose.mTheta };
-            csm_host_inverse_compound(start, end, f.initial_pose);
+        for (std::int32_t k = 0; k < members; ++k) {
+            std::int32_t lo = 0, hi = 0;
+            csm_shard_bounds(n, k, members, &lo, &hi);
+            csm_ctx* ctx = csm_group_member(this->mGroup, k);
+            for (std::int32_t i = lo; i < hi; ++i) {
+                const LoopDetectionQuery& q = queries[i];
+                const GridMapView& g = q.mReferenceLocalMap;
+                /* a loop detector only sees finished local maps, which have an id and never
+                 * change (Assert(localMap.mFinished), loop_detector_branch_bound.cpp:77) */
+                if (g.mId == GridMapView::kInvalidId) {
+                    std::fprintf(stderr, "Assertion failed: reference local map without an id at %s:%d\n",
+                                 __FILE__, __LINE__);
+                    std::abort();
+                }
+                /* upload once per id and member (mPrecompMaps, loop_detector_branch_bound.hpp:98) */
+                if (!csm_has_grid(ctx, g.mId))
+                    CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, g.mId, g.mValues, g.mRows, g.mCols));
+                csm_loop_query& f = flat[i];
+                f.map_id = g.mId;
+                f.geometry = { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
+                f.scan = detail::ToScan(q.mQueryScanData);
+                const double start[3] = { q.mReferenceLocalMapNodeGlobalPose.mX,
+                                          q.mReferenceLocalMapNodeGlobalPose.mY,
+                                          q.mReferenceLocalMapNodeGlobalPose.mTheta };
+                const double end[3] = { q.mQueryScanNodeGlobalPose.mX, q.mQueryScanNodeGlobalPose.mY,
+                                        q.mQueryScanNodeGlobalPose.mTheta };
+                csm_host_inverse_compound(start, end, f.initial_pose);
+            }
         }
         csm_bnb_params prm {};
         prm.range_x = this->mRangeX;
@@ -424,8 +454,12 @@ public:
         prm.score_threshold = this->mScoreThreshold;
         prm.known_rate_threshold = this->mKnownRateThreshold;
         std::vector<csm_summary> out(queries.size());
-        CSM_ASSERT_OK(ctx, csm_bnb_match_batch(ctx, flat.data(), static_cast<std::int32_t>(flat.size()),
-                                               &prm, out.data()));
+        const int rc = csm_group_bnb_match_batch(this->mGroup, flat.data(), n, &prm, out.data());
+        if (rc != 0) {
+            std::fprintf(stderr, "Assertion failed: csm_group_bnb_match_batch == 0 (rc %d: %s) at %s:%d\n", rc,
+                         csm_group_last_error(this->mGroup), __FILE__, __LINE__);
+            std::abort();
+        }
         for (std::size_t i = 0; i < queries.size(); ++i) {
             if (!out[i].pose_found)
                 continue;
@@ -440,16 +474,16 @@ public:
 private:
     LoopDetectorBranchBoundHIP(const std::string& name, int nodeHeightMax, double rangeX,
                                double rangeY, double rangeTheta, double scoreThreshold,
-                               double knownRateThreshold, detail::CtxPtr ctx) :
+                               double knownRateThreshold, csm_group* group) :
         mName(name), mNodeHeightMax(nodeHeightMax), mRangeX(rangeX), mRangeY(rangeY),
         mRangeTheta(rangeTheta), mScoreThreshold(scoreThreshold),
-        mKnownRateThreshold(knownRateThreshold), mCtx(std::move(ctx)) { }
+        mKnownRateThreshold(knownRateThreshold), mGroup(group) { }
 
     const std::string mName;
     const int mNodeHeightMax;
     const double mRangeX, mRangeY, mRangeTheta;
     const double mScoreThreshold, mKnownRateThreshold;
-    detail::CtxPtr mCtx;
+    csm_group* mGroup;
 };
 
 /* LoopDetectorCorrelative (the reference's default "RealTimeCorrelative" loop

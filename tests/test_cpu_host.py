@@ -137,3 +137,35 @@ def test_summary_array_record_bytes_layout():
     assert np.array_equal(b, want)
     assert sa.total("candidates") == 7 * sum(range(n)) and len(sa) == n
     assert sa[3]["raw"]["best_theta"] == 6
+
+
+def test_shard_bounds_match_the_python_detector_and_cover_exactly_once():
+    """csm_shard_bounds (the C ABI's contiguous blocks, loop_detector_fpga_parallel.cpp:42-46)
+    against csm_hip.parallel.shard_bounds, for the sizes the configs use and ragged ones."""
+    from csm_hip import api, parallel
+    for n in list(range(0, 40)) + [255, 256, 257, 2047, 2048]:
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = api.host_shard_bounds(n, r, world)
+                assert (lo, hi) == parallel.shard_bounds(n, r, world)
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+    assert api.host_shard_bounds(2048, 3, 8) == (768, 1024)
+    assert api.host_shard_bounds(10, 5, 4) == (0, 0)       # no such member
+
+
+def test_group_create_without_a_gpu_fails_like_a_context():
+    import ctypes as C
+    import numpy as np
+    import torch
+    from csm_hip import _lib
+    lib = _lib.load()
+    g = C.c_void_p()
+    ids = np.zeros(1, np.int32)
+    rc = lib.csm_group_create(ids.ctypes.data_as(C.c_void_p), 1, C.byref(g))
+    if not torch.cuda.is_available():
+        assert rc == _lib.CSM_ENODEV and not g.value
+    elif rc == 0:
+        lib.csm_group_destroy(g)
+    assert lib.csm_group_create(None, 0, C.byref(g)) == _lib.CSM_EINVAL

@@ -33,10 +33,11 @@ def _write_case(path, mode, case, inits, param_i, ranges3, thr, steps=None):
         f.write(g.tobytes())
 
 
-def _run(path):
+def _run(path, env=None):
     import __graft_entry__ as ge
     ge.build()
-    out = subprocess.run([DEMO, path], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([DEMO, path], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr + out.stdout
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -72,6 +73,11 @@ def test_cpp_loop_detector_adapter(tmp_path, oracle):
     for g, w in zip(got, want):
         assert [float.fromhex(v) for v in g["pose"]] == w[1]
         assert float.fromhex(g["score"]) == w[2]
+    # the same detector over a device list (Create(..., deviceIds)): a one-entry list, two
+    # members on GPU 0 (threads + host-staged exchange) and a one-rank RCCL communicator
+    for env in ({"CSM_DEMO_DEVICES": "0"}, {"CSM_DEMO_DEVICES": "0,0"},
+                {"CSM_DEMO_DEVICES": "0", "CSM_GROUP_FORCE_RCCL": "1"}):
+        assert _run(p, env)["results"] == got, env
 
 
 def test_cpp_loop_detector_correlative_adapter(tmp_path, oracle):
