@@ -312,6 +312,77 @@ int  csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries,
  * (the concatenation of src/mapping/loop_detector_fpga_parallel.cpp:53-56). */
 int  csm_copy_last_batch_records(csm_ctx* ctx, csm_result* dst_dev);
 
+/* ---- the step after every search: cost, covariance, sub-cell refinement ----
+ * CostSquareError (inc/mapping/cost_function_square_error.hpp;
+ * src/mapping/cost_function_square_error.cpp:48-195, 232-341: bilinear
+ * interpolation of the four nearest cells, squared error to 1, Gauss-Newton
+ * Hessian, covariance = Hessian^-1 * CovarianceScale) and
+ * ScanMatcherLinearSolver::OptimizePose
+ * (src/mapping/scan_matcher_linear_solver.cpp:66-169: damped Gauss-Newton
+ * steps, lambda halved / doubled between 1e-8 and 1e-4), which every matcher
+ * and loop detector runs on the pose the search returns
+ * (scan_matcher_correlative.cpp:209-219, loop_detector_branch_bound.cpp:123-127).
+ * Batched: one launch for all queries of a Detect() call.
+ *
+ * TOLERANCE (f64, not bit-exact): hit points come from the device's sin / cos,
+ * sums over the beams are tree reductions, and Eigen's 3x3 inverse / column-
+ * pivoting QR are restated from their algorithms. Against the reference's
+ * arithmetic: costs and Hessian entries agree to 1e-10 relative; covariance
+ * entries to 1e-8 relative to the largest entry; a refined pose to 1e-7 (m,
+ * rad) when both sides run the same number of iterations -- the count can
+ * differ when |cost change| lies within 1e-10 of ConvergenceThreshold, or when
+ * a hit point sits within ~1e-12 cells of a cell edge (the bilinear value is
+ * continuous there, its gradient is not). The tests compare at these bounds.
+ *
+ * Map reads are GridMap::ProbabilityOr(row, col, 0.5)
+ * (src/grid_map_new/grid_map.cpp:423-436): 0.5 outside the map or in a block
+ * that was never allocated, the cell's probability (0 for unknown) otherwise.
+ * Allocation is not part of the dense export: pass it with
+ * csm_set_block_allocation. Without it a block counts as allocated iff it
+ * holds a known cell -- exact for maps that were only ever updated (finished
+ * local maps: every update leaves a value >= 1, grid_map.cpp:514-535), not for
+ * a map that was cleared with ResetValues() (the frontend's latest map). */
+typedef struct {
+    double  covariance_scale;       /* CostSquareError: "CovarianceScale" */
+    int32_t iterations_max;         /* "NumOfIterationsMax" */
+    int32_t reserved;
+    double  convergence_threshold;  /* "ConvergenceThreshold" */
+    double  lambda;                 /* the solver object's damping factor when the call starts
+                                       ("InitialLambda" on its first call); every query of a batch
+                                       starts from it (the reference carries it from query to query:
+                                       a change of <= 1e-4 on diagonals of 1e2 and more) */
+} csm_refine_params;
+
+typedef struct {
+    double  normalized_initial_cost;   /* Cost(start) / n_points */
+    double  normalized_cost;           /* Cost(final) / n_points: ScanMatchingSummary::mNormalizedCost */
+    double  sensor_pose[3];            /* where the evaluation started */
+    double  best_sensor_pose[3];
+    double  estimated_pose[3];         /* MoveBackward(best sensor pose, relative sensor pose) */
+    double  covariance[9];             /* row-major, map-local: mEstimatedCovariance */
+    double  hessian[9];                /* at the final pose, undamped */
+    double  lambda;                    /* damping factor after the call */
+    int32_t iterations;
+    int32_t reserved;
+} csm_refine_result;
+
+/* allocated: one byte per block (non-zero = allocated), row-major
+ * [ceil(rows / 2^log2)][ceil(cols / 2^log2)]: GridMap::IsAllocated of any cell
+ * of the block. Null: back to the rule above with this block size. Must be
+ * repeated after the map is uploaded again. */
+int  csm_set_block_allocation(csm_ctx* ctx, uint64_t map_id, int32_t log2_block_size,
+                              const uint8_t* allocated);
+/* Cost / n and ComputeCovariance at sensor_poses[i] (3 doubles per query: the
+ * best sensor pose of the search), scan and map of queries[i] (initial_pose is
+ * not read). */
+int  csm_cost_covariance_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_queries,
+                               const double* sensor_poses, double covariance_scale,
+                               csm_refine_result* out);
+/* ScanMatcherLinearSolver::OptimizePose for every query: queries[i].initial_pose
+ * is the map-local ROBOT pose to refine (the search's mEstimatedPose). */
+int  csm_linear_solver_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_queries,
+                             const csm_refine_params* params, csm_refine_result* out);
+
 /* ---- several GPUs behind one detector object, in one process ----
  * The reference's precedent is LoopDetectorFPGAParallel
  * (src/mapping/loop_detector_fpga_parallel.cpp:42-56): Detect() cuts the query

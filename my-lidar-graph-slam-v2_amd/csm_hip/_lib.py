@@ -103,6 +103,19 @@ class Summary(C.Structure):
                 ("candidates", C.c_int64), ("raw", Result)]
 
 
+class RefineParams(C.Structure):
+    _fields_ = [("covariance_scale", C.c_double), ("iterations_max", C.c_int32), ("reserved", C.c_int32),
+                ("convergence_threshold", C.c_double), ("lambda_", C.c_double)]
+
+
+class RefineResult(C.Structure):
+    _fields_ = [("normalized_initial_cost", C.c_double), ("normalized_cost", C.c_double),
+                ("sensor_pose", C.c_double * 3), ("best_sensor_pose", C.c_double * 3),
+                ("estimated_pose", C.c_double * 3), ("covariance", C.c_double * 9),
+                ("hessian", C.c_double * 9), ("lambda_", C.c_double), ("iterations", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class LoopQuery(C.Structure):
     _fields_ = [("map_id", C.c_uint64), ("geometry", Geometry), ("scan", Scan),
                 ("initial_pose", C.c_double * 3)]
@@ -170,6 +183,10 @@ SIGNATURES = {
     "csm_host_map_resize": (C.c_int, [_P(MapShape), C.c_void_p, C.c_int32, C.c_void_p]),
     "csm_update_map_with_scan": (C.c_int, [_ctx, C.c_uint64, _P(MapShape), C.c_void_p, _P(ScanNode),
                                            _P(MapBuilderParams), _P(MapBuildInfo)]),
+    "csm_set_block_allocation": (C.c_int, [_ctx, C.c_uint64, C.c_int32, C.c_void_p]),
+    "csm_cost_covariance_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32, C.c_void_p, C.c_double,
+                                            _P(RefineResult)]),
+    "csm_linear_solver_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32, _P(RefineParams), _P(RefineResult)]),
     "csm_shard_bounds": (None, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "csm_group_create": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p)]),
     "csm_group_destroy": (C.c_int, [C.c_void_p]),

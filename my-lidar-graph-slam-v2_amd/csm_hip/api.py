@@ -428,6 +428,39 @@ class Context:
         self._check(self.lib.csm_bnb_match_batch(self._ctx, prep.arr, prep.n, C.byref(p), out))
         return SummaryArray(out) if as_records else [summary_to_dict(o) for o in out]
 
+    def set_block_allocation(self, map_id, log2_block_size, allocated):
+        """csm_set_block_allocation: uint8 [block rows, block cols] (None: derive from the cells)."""
+        a = None if allocated is None else np.ascontiguousarray(allocated, dtype=np.uint8)
+        self._check(self.lib.csm_set_block_allocation(self._ctx, map_id, log2_block_size,
+                                                      None if a is None else _ptr(a)))
+
+    @staticmethod
+    def _refine_to_dict(r):
+        return dict(normalized_initial_cost=r.normalized_initial_cost, normalized_cost=r.normalized_cost,
+                    sensor_pose=list(r.sensor_pose), best_sensor_pose=list(r.best_sensor_pose),
+                    estimated_pose=list(r.estimated_pose),
+                    covariance=np.array(r.covariance).reshape(3, 3),
+                    hessian=np.array(r.hessian).reshape(3, 3), lambda_=r.lambda_, iterations=r.iterations)
+
+    def cost_covariance_batch(self, queries, sensor_poses, covariance_scale=1e4):
+        """CostSquareError::Cost / n and ComputeCovariance at the given sensor poses."""
+        prep = self.prepare_queries(queries)
+        sp = _f64(sensor_poses).reshape(prep.n, 3)
+        out = (L.RefineResult * prep.n)()
+        self._check(self.lib.csm_cost_covariance_batch(self._ctx, prep.arr, prep.n, _ptr(sp),
+                                                       covariance_scale, out))
+        return [self._refine_to_dict(o) for o in out]
+
+    def linear_solver_batch(self, queries, iterations_max=10, convergence_threshold=1e-4, lambda_=1e-4,
+                            covariance_scale=1e4):
+        """ScanMatcherLinearSolver::OptimizePose per query (init_pose = robot pose to refine);
+        defaults as launcher_settings_default.json:28-35, 11-13."""
+        prep = self.prepare_queries(queries)
+        p = L.RefineParams(covariance_scale, iterations_max, 0, convergence_threshold, lambda_)
+        out = (L.RefineResult * prep.n)()
+        self._check(self.lib.csm_linear_solver_batch(self._ctx, prep.arr, prep.n, C.byref(p), out))
+        return [self._refine_to_dict(o) for o in out]
+
     def enable_kernel_timing(self, on=True):
         self._check(self.lib.csm_enable_kernel_timing(self._ctx, 1 if on else 0))
 

@@ -27,6 +27,7 @@
 
 #include "csm_kernels.hip"
 #include "csm_map_kernels.hip"
+#include "csm_cost_kernels.hip"
 
 using namespace csm;
 
@@ -57,6 +58,12 @@ struct DeviceGrid {
     size_t xg_cap = 0;
     int xg_pad = 0, xg_pitch = 0;
     bool xg_stale = true;
+    /* block-allocation bitmap for the cost function's ProbabilityOr(.., 0.5): one byte per
+     * block; the caller's (csm_set_block_allocation) or derived from the cells */
+    uint8_t* alloc = nullptr;
+    size_t alloc_cap = 0;
+    int alloc_log2 = 0, alloc_bcols = 0;
+    bool alloc_user = false, alloc_stale = true;
 };
 
 struct TimedSpan {
@@ -82,6 +89,10 @@ struct csm_ctx {
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
+    /* cost / refinement batches: device scans + job table, host staging */
+    DevBuf c_scans, c_jobs;
+    std::vector<double> c_stage;
+    std::vector<csm::CostJob> c_job_stage;
     /* the final records of the last batch call in query order (csm_copy_last_batch_records) */
     DevBuf rec_dev;
     int rec_n = 0;
@@ -692,6 +703,12 @@ void free_levels(DeviceGrid& g, bool keep_base)
         g.xg = nullptr;
         g.xg_cap = 0;
         g.xg_stale = true;
+        if (g.alloc)
+            (void)hipFree(g.alloc);
+        g.alloc = nullptr;
+        g.alloc_cap = 0;
+        g.alloc_user = false;
+        g.alloc_stale = true;
     }
     for (size_t i = keep_base ? 1 : 0; i < g.levels.size(); ++i)
         if (g.levels[i].owned && g.levels[i].cells)
@@ -1250,7 +1267,7 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
-                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev,
+                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
     for (DevBuf* b : bufs)
         if (b->p)
@@ -2872,4 +2889,5 @@ int csm_reset_kernel_timing(csm_ctx* ctx)
 
 } /* extern "C" */
 
+#include "csm_cost_api.hip"
 #include "csm_group.hip"

@@ -324,5 +324,29 @@ struct MapJob {
     int32_t keep_cells;        /* 1: the updates go on top of the cells' values (UpdateGridMap) */
 };
 
+/* cost / covariance / linear-solver refinement (csm_cost_kernels.hip) */
+struct CostOut {
+    double initial_cost, cost;           /* sums over the beams, not normalized */
+    double best_sensor_pose[3];
+    double hessian[9], residual[3];      /* at the final pose, without the damping term */
+    double covariance[9];
+    double lambda;
+    int32_t iterations, pad;
+};
+struct CostJob {
+    const uint16_t* cells;
+    int32_t rows, cols, pitch;
+    int32_t log2_block, block_cols;
+    const uint8_t* alloc;                /* one byte per block, null = all allocated */
+    double res, off_x, off_y;
+    const double* angles;
+    const double* ranges;
+    int32_t n, iterations_max;
+    double sensor_pose[3];
+    double convergence_threshold, lambda, covariance_scale;
+    const double* lut;
+    CostOut* out;
+};
+
 } /* namespace csm */
 #endif

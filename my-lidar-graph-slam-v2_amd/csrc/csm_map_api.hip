@@ -388,6 +388,8 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
             g.levels[i].cells = g.levels[0].cells;     /* an alias of the base (window 1) */
     }
     g.xg_stale = true;         /* the pair-row copy follows the base */
+    g.alloc_stale = true;      /* and so does the derived block-allocation bitmap */
+    g.alloc_user = false;
     g.rows = rows;
     g.cols = cols;
     g.pitch = pitch;

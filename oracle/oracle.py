@@ -372,3 +372,79 @@ def bayes_update(value, prob):
     lib().orc_bayes_update.restype = C.c_uint
     lib().orc_bayes_update.argtypes = [C.c_uint, C.c_double]
     return lib().orc_bayes_update(value, prob)
+
+
+# ---- cost / covariance / linear-solver refinement (oracle/cost_oracle.cpp) ----
+
+class CostGrid(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("res", C.c_double),
+                ("offX", C.c_double), ("offY", C.c_double), ("alloc", C.c_void_p), ("log2Block", C.c_int)]
+
+
+class RefineResult(C.Structure):
+    _fields_ = [("normalizedInitialCost", C.c_double), ("normalizedCost", C.c_double),
+                ("sensorPose", C.c_double * 3), ("bestSensorPose", C.c_double * 3),
+                ("estimatedPose", C.c_double * 3), ("covariance", C.c_double * 9),
+                ("lambda_", C.c_double), ("iterations", C.c_int)]
+
+
+def _cost_grid(grid, geom, alloc=None, log2_block=4):
+    g = np.ascontiguousarray(grid, dtype=np.uint16)
+    a = None if alloc is None else np.ascontiguousarray(alloc, dtype=np.uint8)
+    cg = CostGrid(g.ctypes.data, g.shape[0], g.shape[1], geom[0], geom[1], geom[2],
+                  None if a is None else a.ctypes.data, log2_block)
+    return cg, (g, a)
+
+
+def cost(grid, geom, angles, ranges, sensor_pose, alloc=None, log2_block=4):
+    """CostSquareError::Cost (sum of squared errors, not normalized)."""
+    cg, keep = _cost_grid(grid, geom, alloc, log2_block)
+    a, r = _f64(angles), _f64(ranges)
+    lib().orc_cost.restype = C.c_double
+    return lib().orc_cost(C.byref(cg), _p(a), _p(r), a.size, _p(_f64(sensor_pose)))
+
+
+def hessian_residual(grid, geom, angles, ranges, sensor_pose, alloc=None, log2_block=4):
+    cg, keep = _cost_grid(grid, geom, alloc, log2_block)
+    a, r = _f64(angles), _f64(ranges)
+    h, res = np.zeros(9), np.zeros(3)
+    lib().orc_hessian_residual(C.byref(cg), _p(a), _p(r), a.size, _p(_f64(sensor_pose)), _p(h), _p(res))
+    return h.reshape(3, 3), res
+
+
+def covariance(grid, geom, angles, ranges, sensor_pose, covariance_scale=1e4, alloc=None, log2_block=4):
+    cg, keep = _cost_grid(grid, geom, alloc, log2_block)
+    a, r = _f64(angles), _f64(ranges)
+    cov = np.zeros(9)
+    lib().orc_covariance(C.byref(cg), _p(a), _p(r), a.size, _p(_f64(sensor_pose)),
+                         C.c_double(covariance_scale), _p(cov))
+    return cov.reshape(3, 3)
+
+
+def inverse3(m):
+    out = np.zeros(9)
+    lib().orc_inverse3(_p(_f64(m).reshape(-1)), _p(out))
+    return out.reshape(3, 3)
+
+
+def solve3(m, b):
+    x = np.zeros(3)
+    lib().orc_solve3_colpiv_qr(_p(_f64(m).reshape(-1)), _p(_f64(b)), _p(x))
+    return x
+
+
+def linear_solver(grid, geom, angles, ranges, rel_pose, init_pose, iterations_max=10,
+                  convergence_threshold=1e-4, lambda_=1e-4, covariance_scale=1e4, alloc=None,
+                  log2_block=4):
+    """ScanMatcherLinearSolver::OptimizePose; defaults as launcher_settings_default.json:28-35, 11-13."""
+    cg, keep = _cost_grid(grid, geom, alloc, log2_block)
+    a, r = _f64(angles), _f64(ranges)
+    out = RefineResult()
+    lib().orc_linear_solver(C.byref(cg), _p(a), _p(r), a.size, _p(_f64(rel_pose)), _p(_f64(init_pose)),
+                            iterations_max, C.c_double(convergence_threshold), C.c_double(lambda_),
+                            C.c_double(covariance_scale), C.byref(out))
+    return dict(normalized_initial_cost=out.normalizedInitialCost, normalized_cost=out.normalizedCost,
+                sensor_pose=list(out.sensorPose), best_sensor_pose=list(out.bestSensorPose),
+                estimated_pose=list(out.estimatedPose),
+                covariance=np.array(out.covariance).reshape(3, 3), lambda_=out.lambda_,
+                iterations=out.iterations)
