@@ -187,6 +187,9 @@ int main(int argc, char** argv)
         std::printf("{\"error\": \"no device\"}\n");
         return 3;
     }
+    const bool refine = std::getenv("CSM_DEMO_REFINE") != nullptr;   /* the detector's final matcher */
+    if (d && refine)
+        d->UseFinalScanMatcher();
     g.mId = 42;
     LoopDetectionQueryVector qs;
     for (int i = 0; i < nq; ++i) {
@@ -202,9 +205,11 @@ int main(int argc, char** argv)
     const LoopDetectionResultVector rs = d ? d->Detect(qs) : dc->Detect(qs);
     std::printf("{\"results\": [");
     for (size_t i = 0; i < rs.size(); ++i)
-        std::printf("%s{\"node\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\"}", i ? ", " : "",
+        std::printf("%s{\"node\": %d, \"pose\": [\"%a\", \"%a\", \"%a\"], \"score\": \"%a\", "
+                    "\"cost\": \"%a\", \"cov00\": \"%a\"}", i ? ", " : "",
                     rs[i].mScanNodeId, rs[i].mRelativePose.mX, rs[i].mRelativePose.mY,
-                    rs[i].mRelativePose.mTheta, rs[i].mScoreValue);
+                    rs[i].mRelativePose.mTheta, rs[i].mScoreValue, rs[i].mNormalizedCost,
+                    rs[i].mEstimatedCovariance[0]);
     std::printf("]}\n");
     return 0;
 }

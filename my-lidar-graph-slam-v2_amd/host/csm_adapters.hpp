@@ -355,7 +355,10 @@ struct LoopDetectionQuery {
 };
 using LoopDetectionQueryVector = std::vector<LoopDetectionQuery>;
 
-/* inc/mapping/loop_detector.hpp:58-92 before the final sub-pixel matcher */
+/* inc/mapping/loop_detector.hpp:58-92. Without a final matcher
+ * (UseFinalScanMatcher) mRelativePose is the search's estimate and the
+ * covariance is zero; with one they are ScanMatcherLinearSolver's
+ * (loop_detector_branch_bound.cpp:123-135). */
 struct LoopDetectionResult {
     RobotPose2D<double> mRelativePose;   /* estimated pose, map-local */
     RobotPose2D<double> mLocalMapPose;
@@ -363,6 +366,8 @@ struct LoopDetectionResult {
     int mScanNodeId;
     double mScoreValue;
     std::uint32_t mFlags;
+    double mEstimatedCovariance[9] = { 0 };   /* row-major */
+    double mNormalizedCost = 0.0;
 };
 using LoopDetectionResultVector = std::vector<LoopDetectionResult>;
 
@@ -406,6 +411,19 @@ public:
 
     const std::string& Name() const { return this->mName; }
     int NumOfDevices() const { return csm_group_size(this->mGroup); }
+
+    /* The detector's final matcher, ScanMatcherLinearSolver on CostSquareError
+     * ("FinalScanMatcherLinearSolver", launcher_settings_default.json:148-155, 11-13),
+     * run on the device for all found queries of a Detect() call. */
+    void UseFinalScanMatcher(int numOfIterationsMax = 10, double convergenceThreshold = 1e-4,
+                             double initialLambda = 1e-4, double covarianceScale = 1e4)
+    {
+        this->mRefine = true;
+        this->mRefineParams.iterations_max = numOfIterationsMax;
+        this->mRefineParams.convergence_threshold = convergenceThreshold;
+        this->mRefineParams.lambda = initialLambda;
+        this->mRefineParams.covariance_scale = covarianceScale;
+    }
 
     /* LoopDetector::Detect: results only for the queries where a pose was
      * found, in query order (loop_detector_branch_bound.cpp:107-135). */
@@ -460,13 +478,52 @@ public:
                          csm_group_last_error(this->mGroup), __FILE__, __LINE__);
             std::abort();
         }
+        /* the final matcher on every estimate that was found, member by member (each member
+         * holds the maps of its own block): loop_detector_branch_bound.cpp:119-127 */
+        std::vector<csm_refine_result> refined(queries.size());
+        if (this->mRefine) {
+            for (std::int32_t k = 0; k < members; ++k) {
+                std::int32_t lo = 0, hi = 0;
+                csm_shard_bounds(n, k, members, &lo, &hi);
+                std::vector<csm_loop_query> second;
+                std::vector<std::int32_t> index;
+                for (std::int32_t i = lo; i < hi; ++i) {
+                    if (!out[i].pose_found)
+                        continue;
+                    csm_loop_query q = flat[i];
+                    for (int c = 0; c < 3; ++c)
+                        q.initial_pose[c] = out[i].estimated_pose[c];
+                    second.push_back(q);
+                    index.push_back(i);
+                }
+                if (second.empty())
+                    continue;
+                std::vector<csm_refine_result> res(second.size());
+                csm_ctx* ctx = csm_group_member(this->mGroup, k);
+                CSM_ASSERT_OK(ctx, csm_linear_solver_batch(ctx, second.data(),
+                                                           static_cast<std::int32_t>(second.size()),
+                                                           &this->mRefineParams, res.data()));
+                for (std::size_t j = 0; j < index.size(); ++j)
+                    refined[index[j]] = res[j];
+                /* the solver object keeps its damping factor between calls */
+                this->mRefineParams.lambda = res.back().lambda;
+            }
+        }
         for (std::size_t i = 0; i < queries.size(); ++i) {
             if (!out[i].pose_found)
                 continue;
-            results.push_back(LoopDetectionResult {
+            LoopDetectionResult r {
                 { out[i].estimated_pose[0], out[i].estimated_pose[1], out[i].estimated_pose[2] },
                 queries[i].mReferenceLocalMapNodeGlobalPose, queries[i].mReferenceLocalMap.mId,
-                queries[i].mQueryScanNodeId, out[i].raw.score, out[i].raw.flags });
+                queries[i].mQueryScanNodeId, out[i].raw.score, out[i].raw.flags };
+            if (this->mRefine) {
+                r.mRelativePose = { refined[i].estimated_pose[0], refined[i].estimated_pose[1],
+                                    refined[i].estimated_pose[2] };
+                for (int c = 0; c < 9; ++c)
+                    r.mEstimatedCovariance[c] = refined[i].covariance[c];
+                r.mNormalizedCost = refined[i].normalized_cost;
+            }
+            results.push_back(r);
         }
         return results;
     }
@@ -484,6 +541,8 @@ private:
     const double mRangeX, mRangeY, mRangeTheta;
     const double mScoreThreshold, mKnownRateThreshold;
     csm_group* mGroup;
+    bool mRefine = false;
+    csm_refine_params mRefineParams {};
 };
 
 /* LoopDetectorCorrelative (the reference's default "RealTimeCorrelative" loop

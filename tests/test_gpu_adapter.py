@@ -78,6 +78,20 @@ def test_cpp_loop_detector_adapter(tmp_path, oracle):
     for env in ({"CSM_DEMO_DEVICES": "0"}, {"CSM_DEMO_DEVICES": "0,0"},
                 {"CSM_DEMO_DEVICES": "0", "CSM_GROUP_FORCE_RCCL": "1"}):
         assert _run(p, env)["results"] == got, env
+    # with the detector's final matcher (UseFinalScanMatcher): pose, cost and covariance of
+    # ScanMatcherLinearSolver on the search's estimate, at the header's tolerance
+    fin = _run(p, {"CSM_DEMO_REFINE": "1", "CSM_DEMO_DEVICES": "0,0"})["results"]
+    assert [g["node"] for g in fin] == [w[0] for w in want]
+    alloc = (case["grid"].reshape(25, 16, 25, 16).max(axis=(1, 3)) > 0).astype(np.uint8)
+    lam = 1e-4
+    for g, w in zip(fin, want):
+        r = oracle.linear_solver(case["grid"], case["geom"], case["angles"], case["ranges"], case["rel_pose"],
+                                 w[1], lambda_=lam, alloc=alloc)
+        lam = r["lambda_"]                     # the solver object keeps its damping factor
+        got_pose = np.array([float.fromhex(v) for v in g["pose"]])
+        assert np.all(np.abs(got_pose - np.array(r["estimated_pose"])) < 1e-6)
+        assert abs(float.fromhex(g["cost"]) - r["normalized_cost"]) < 1e-8
+        assert abs(float.fromhex(g["cov00"]) - r["covariance"][0, 0]) < 1e-6 * abs(r["covariance"][0, 0])
 
 
 def test_cpp_loop_detector_correlative_adapter(tmp_path, oracle):

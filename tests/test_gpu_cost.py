@@ -69,7 +69,7 @@ def test_linear_solver_batch(gpu_ctx, oracle):
                                  q["init_pose"], 10, 1e-4, 1e-4, 1e4, alloc=alloc)
         assert g["sensor_pose"] == w["sensor_pose"]            # Compound on the host: bit-exact
         assert abs(g["normalized_initial_cost"] - w["normalized_initial_cost"]) <= REL_COST * w["normalized_initial_cost"]
-        assert g["normalized_cost"] <= g["normalized_initial_cost"]
+        # (the reference accepts every damped Gauss-Newton step: the cost may also rise)
         if g["iterations"] != w["iterations"]:
             continue        # |cost change| on the convergence threshold: allowed, must stay rare
         same += 1
