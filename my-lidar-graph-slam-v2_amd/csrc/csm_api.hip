@@ -90,7 +90,8 @@ struct csm_ctx {
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     /* cost / refinement batches: device scans + job table, host staging */
-    DevBuf c_scans, c_jobs;
+    DevBuf c_scans, c_jobs, box_jobs;
+    std::vector<csm::BoxJob> box_stage;
     std::vector<double> c_stage;
     std::vector<csm::CostJob> c_job_stage;
     /* the final records of the last batch call in query order (csm_copy_last_batch_records) */
@@ -716,37 +717,64 @@ void free_levels(DeviceGrid& g, bool keep_base)
     g.levels.resize(keep_base && !g.levels.empty() ? 1 : 0);
 }
 
-/* `reuse`: a buffer of at least rows*pitch*2 bytes to build into (its capacity
- * in *reuse_cap), or null to allocate one */
+/* Box-maximum levels to build: collected first, launched together (launch_box_jobs). */
+struct PendingBox {
+    DeviceGrid* grid;
+    int level;          /* index into grid->levels: its cells are the destination */
+};
+
+/* One launch for all pending levels (k_boxmax_batch). The job table is uploaded
+ * from context-owned host memory. */
+int launch_box_jobs(csm_ctx* ctx, const std::vector<PendingBox>& pending)
+{
+    if (pending.empty())
+        return CSM_OK;
+    ctx->box_stage.resize(pending.size());
+    int rows_max = 0, pitch_max = 0;
+    for (size_t i = 0; i < pending.size(); ++i) {
+        const DeviceGrid& g = *pending[i].grid;
+        BoxJob& b = ctx->box_stage[i];
+        b.src = g.levels[0].cells;
+        b.dst = g.levels[pending[i].level].cells;
+        b.rows = g.rows;
+        b.cols = g.cols;
+        b.pitch = g.pitch;
+        b.win = g.levels[pending[i].level].win;
+        rows_max = std::max(rows_max, g.rows);
+        pitch_max = std::max(pitch_max, g.pitch);
+    }
+    int rc = ensure(ctx, ctx->box_jobs, pending.size() * sizeof(BoxJob));
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->box_jobs.p, ctx->box_stage.data(), pending.size() * sizeof(BoxJob),
+                                hipMemcpyHostToDevice, ctx->stream));
+    ScopedTimer tm(ctx, "boxmax");
+    for (size_t first = 0; first < pending.size(); first += 65535) {      /* grid.z limit */
+        const unsigned nz = (unsigned)std::min<size_t>(65535, pending.size() - first);
+        hipLaunchKernelGGL(k_boxmax_batch, dim3(ceil_div(pitch_max, kBoxTC), ceil_div(rows_max, kBoxTR), nz),
+                           dim3(256), 0, ctx->stream, reinterpret_cast<const BoxJob*>(ctx->box_jobs.p) + first);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
+/* Prepares level `win` of g for building: allocates (or reuses) its buffer and
+ * records it in `pending`; the caller launches. `reuse`: a buffer of at least
+ * rows * pitch * 2 bytes to build into, or null to allocate one. */
 int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out, uint16_t* reuse = nullptr,
                 size_t reuse_cap = 0)
 {
     if (win < 1 || win > g.rows || win > g.cols)
         return fail(ctx, CSM_EINVAL, "box-max window %d does not fit %dx%d", win, g.rows, g.cols);
+    if (win > kBoxMaxWin)
+        return fail(ctx, CSM_EINVAL, "box-max window %d exceeds %d", win, kBoxMaxWin);
     const size_t bytes = (size_t)g.rows * g.pitch * 2;
-    int rc = ensure(ctx, ctx->scratch, bytes);
-    if (rc)
-        return rc;
     uint16_t* dst = reuse;
     size_t cap = reuse_cap;
     if (!dst) {
         if (hipMalloc(reinterpret_cast<void**>(&dst), bytes) != hipSuccess)
             return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
         cap = bytes;
-    }
-    const dim3 grid(ceil_div(g.pitch, kBlock), g.rows);
-    {
-        ScopedTimer tm(ctx, "boxmax");
-        hipLaunchKernelGGL(k_boxmax_v, grid, dim3(kBlock), 0, ctx->stream, g.levels[0].cells,
-                           reinterpret_cast<uint16_t*>(ctx->scratch.p), g.rows, g.cols, g.pitch, win);
-        hipLaunchKernelGGL(k_boxmax_h, grid, dim3(kBlock), 0, ctx->stream,
-                           reinterpret_cast<const uint16_t*>(ctx->scratch.p), dst, g.rows, g.cols,
-                           g.pitch, win);
-    }
-    if (hipGetLastError() != hipSuccess) {
-        if (!reuse)
-            (void)hipFree(dst);
-        return fail(ctx, CSM_EIO, "box-max launch failed");
     }
     out->win = win;
     out->cells = dst;
@@ -756,9 +784,15 @@ int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out, uint16_t* reus
     return CSM_OK;
 }
 
-/* index of the level with this window; builds and appends it if missing */
-int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index)
+/* index of the level with this window; builds and appends it if missing. With
+ * `pending` the launch is left to the caller (launch_box_jobs), so that many
+ * levels of many maps share one launch. */
+int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index,
+                     std::vector<PendingBox>* pending = nullptr)
 {
+    std::vector<PendingBox> local;
+    std::vector<PendingBox>& todo = pending ? *pending : local;
+    auto finish = [&]() { return pending ? CSM_OK : launch_box_jobs(ctx, local); };
     for (size_t i = 0; i < g.levels.size(); ++i)
         if (g.levels[i].win == win) {
             Level& have = g.levels[i];
@@ -778,9 +812,10 @@ int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index)
                 if (rc)
                     return rc;
                 have = fresh;
+                todo.push_back({ &g, (int)i });
             }
             *index = (int)i;
-            return CSM_OK;
+            return finish();
         }
     Level lv;
     int rc = build_level(ctx, g, win, &lv);
@@ -788,7 +823,8 @@ int level_for_window(csm_ctx* ctx, DeviceGrid& g, int win, int* index)
         return rc;
     g.levels.push_back(lv);
     *index = (int)g.levels.size() - 1;
-    return CSM_OK;
+    todo.push_back({ &g, *index });
+    return finish();
 }
 
 /* The pair-row copy of level 0 with at least `need_pad` cells of zero padding. */
@@ -1267,7 +1303,7 @@ int csm_destroy(csm_ctx* ctx)
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
                        &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
-                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs,
+                       &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs, &ctx->box_jobs,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
     for (DevBuf* b : bufs)
         if (b->p)
@@ -1402,6 +1438,13 @@ int csm_build_pyramid(csm_ctx* ctx, uint64_t map_id, const int32_t* win_sizes, i
         lv.push_back(l);
     }
     g->levels = lv;
+    std::vector<PendingBox> pending;
+    for (int i = 1; i < n_levels; ++i)
+        if (g->levels[i].owned)
+            pending.push_back({ g, i });
+    int rc = launch_box_jobs(ctx, pending);
+    if (rc)
+        return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CSM_OK;
 }
@@ -2429,6 +2472,7 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
     /* pyramids: build and cache per map id, as mPrecompMaps does
      * (loop_detector_branch_bound.cpp:83-89) */
     std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
+    std::vector<PendingBox> pending_levels;
     for (int i = 0; i < n_queries; ++i) {
         if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
             return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
@@ -2439,12 +2483,17 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
             return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
                         (unsigned long long)queries[i].map_id);
         for (int h = 0; h <= H; ++h) {
-            int rc = level_for_window(ctx, *g, 1 << h, &levels[i][h]);
+            int rc = level_for_window(ctx, *g, 1 << h, &levels[i][h], &pending_levels);
             if (rc)
                 return rc;
         }
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        /* all missing levels of all maps: one launch */
+        int rc = launch_box_jobs(ctx, pending_levels);
+        if (rc)
+            return rc;
+    }
     const auto t1 = std::chrono::steady_clock::now();
 
     /* group queries by leaf-window shape */
@@ -2503,6 +2552,7 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
             return rc;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    std::vector<PendingBox> pending_levels;
     std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
     for (int i = 0; i < n_queries; ++i) {
         if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
@@ -2514,12 +2564,16 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
             return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
                         (unsigned long long)queries[i].map_id);
         if (H) {
-            int rc = level_for_window(ctx, *g, L, &levels[i][1]);
+            int rc = level_for_window(ctx, *g, L, &levels[i][1], &pending_levels);
             if (rc)
                 return rc;
         }
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        int rc = launch_box_jobs(ctx, pending_levels);
+        if (rc)
+            return rc;
+    }
     const auto t1 = std::chrono::steady_clock::now();
     std::memset(out, 0, sizeof(csm_summary) * (size_t)n_queries);
     std::map<std::pair<int, int>, std::vector<int>> groups;
@@ -2821,18 +2875,19 @@ int csm_build_pyramids(csm_ctx* ctx, const uint64_t* map_ids, int32_t n_maps, co
     if (!ctx || !map_ids || n_maps < 1 || !win_sizes || n_levels < 1)
         return fail(ctx, CSM_EINVAL, "csm_build_pyramids: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<PendingBox> pending;
     for (int i = 0; i < n_maps; ++i) {
         DeviceGrid* g = find_grid(ctx, map_ids[i]);
         if (!g)
             return fail(ctx, CSM_ENOENT, "map %llu not resident", (unsigned long long)map_ids[i]);
         for (int l = 0; l < n_levels; ++l) {
             int index = 0;
-            int rc = level_for_window(ctx, *g, win_sizes[l], &index);
+            int rc = level_for_window(ctx, *g, win_sizes[l], &index, &pending);
             if (rc)
                 return rc;
         }
     }
-    return CSM_OK;
+    return launch_box_jobs(ctx, pending);      /* all levels of all maps: one launch */
 }
 
 /* ---- measurement hooks ---- */

@@ -83,6 +83,13 @@ struct BinJob {
     int32_t band_nx[kMaxElig], band_ny[kMaxElig];
 };
 
+/* k_boxmax_batch: dst = box maximum (win x win, tail rule) of src; same rows / cols / pitch */
+struct BoxJob {
+    const uint16_t* src;
+    uint16_t* dst;
+    int32_t rows, cols, pitch, win;
+};
+
 /* k_zero_if_band: clear a[0..words) (and b) when the query's band flag is set */
 struct ZeroJob {
     uint32_t* a;

@@ -14,9 +14,10 @@
  *                src/mapping/scan_matcher_correlative.cpp:161-197, 301-368 and
  *                ScorePixelAccurate::Score per branch-and-bound node
  *                (src/mapping/score_function_pixel_accurate.cpp:16-58).
- * K2 k_boxmax_*  forward box maximum with the reference's "repeat the last
+ * K2 k_boxmax_batch  forward box maximum with the reference's "repeat the last
  *                window" edge rule (inc/util.hpp:369-424,
- *                src/mapping/grid_map_builder.cpp:918-984).
+ *                src/mapping/grid_map_builder.cpp:918-984), all levels of all
+ *                maps of a call in one launch.
  * K4 k_finalize  reduces the workgroup records, replays the winner in f64 in
  *                beam order (bit-exact scoreMax), writes the result record.
  *
@@ -1106,39 +1107,60 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob*
 }
 
 /* ------------------------------------------------------------------ K2 */
-/* out[r][c] = max_{k<w} in[min(r, rows-w)+k][c]; pad columns stay 0 */
-__global__ __launch_bounds__(kBlock) void k_boxmax_v(const uint16_t* in, uint16_t* out,
-                                                    int rows, int cols, int pitch, int w)
-{
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= pitch)
-        return;
-    uint16_t m = 0;
-    if (c < cols) {
-        const int r0 = min(r, rows - w);
-        for (int k = 0; k < w; ++k)
-            m = max(m, in[(size_t)(r0 + k) * pitch + c]);
-    }
-    out[(size_t)r * pitch + c] = m;
-}
+/* Forward box maximum with the reference's tail rule, both passes in one
+ * kernel, any number of (map, window) jobs in one launch:
+ *   out[r][c] = max{ in[r'][c'] : s(r) <= r' < s(r) + W, s(c) <= c' < s(c) + W },
+ *   s(i) = min(i, n - W)   ("repeat the last full window", inc/util.hpp:421-423)
+ * which is SlidingWindowMaxRow then SlidingWindowMaxCol of
+ * src/mapping/grid_map_builder.cpp:918-984 (a maximum of maxima; both orders
+ * give the same bytes). A workgroup computes a 32 x 64 output tile: the input
+ * rows / columns it needs form one contiguous range of at most 32 + W - 1 /
+ * 64 + W - 1, staged in LDS; vertical maxima into a second LDS array, then
+ * horizontal maxima to memory. Pad columns (cols..pitch) are written 0.
+ * grid = (column tiles, row tiles, jobs). */
+constexpr int kBoxTR = 32, kBoxTC = 64, kBoxMaxWin = 64;
 
-/* out[r][c] = max_{k<w} in[r][min(c, cols-w)+k] */
-__global__ __launch_bounds__(kBlock) void k_boxmax_h(const uint16_t* in, uint16_t* out,
-                                                    int rows, int cols, int pitch, int w)
+__global__ __launch_bounds__(256) void k_boxmax_batch(const BoxJob* jobs)
 {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= pitch)
+    __shared__ uint16_t tile[(kBoxTR + kBoxMaxWin - 1) * (kBoxTC + kBoxMaxWin)];
+    __shared__ uint16_t mid[kBoxTR * (kBoxTC + kBoxMaxWin)];
+    const BoxJob j = jobs[blockIdx.z];
+    const int r0 = blockIdx.y * kBoxTR, c0 = blockIdx.x * kBoxTC;
+    if (r0 >= j.rows || c0 >= j.pitch)
         return;
-    uint16_t m = 0;
-    if (c < cols) {
-        const int c0 = min(c, cols - w);
-        const uint16_t* p = in + (size_t)r * pitch + c0;
-        for (int k = 0; k < w; ++k)
-            m = max(m, p[k]);
+    const int w = j.win;
+    const int tr = min(kBoxTR, j.rows - r0);              /* output rows of this tile */
+    const int tc = min(kBoxTC, j.pitch - c0);             /* output columns incl. pad columns */
+    const int tcv = max(0, min(kBoxTC, j.cols - c0));     /* ... that hold cells */
+    const int in_r0 = min(r0, j.rows - w);
+    const int nr = min(r0 + tr - 1, j.rows - w) + w - in_r0;
+    const int in_c0 = min(c0, j.cols - w);
+    const int nc = tcv > 0 ? min(c0 + tcv - 1, j.cols - w) + w - in_c0 : 0;
+    const int ncp = kBoxTC + kBoxMaxWin;                  /* LDS row pitch */
+    for (int i = threadIdx.x; i < nr * nc; i += 256) {
+        const int r = i / nc, c = i - r * nc;
+        tile[r * ncp + c] = j.src[(size_t)(in_r0 + r) * j.pitch + in_c0 + c];
     }
-    out[(size_t)r * pitch + c] = m;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tr * nc; i += 256) {
+        const int r = i / nc, c = i - r * nc;
+        const int s = min(r0 + r, j.rows - w) - in_r0;
+        uint16_t m = 0;
+        for (int k = 0; k < w; ++k)
+            m = max(m, tile[(s + k) * ncp + c]);
+        mid[r * ncp + c] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tr * tc; i += 256) {
+        const int r = i / tc, c = i - r * tc;
+        uint16_t m = 0;
+        if (c < tcv) {
+            const int s = min(c0 + c, j.cols - w) - in_c0;
+            for (int k = 0; k < w; ++k)
+                m = max(m, mid[r * ncp + s + k]);
+        }
+        j.dst[(size_t)(r0 + r) * j.pitch + c0 + c] = m;
+    }
 }
 
 /* ------------------------------------------------------------------ K4 */
