@@ -65,11 +65,19 @@ struct RobotPose2D {
  * LocalMapId::Invalid does in scan_matcher_correlative_fpga.cpp:177-184. */
 struct GridMapView {
     static constexpr std::uint64_t kInvalidId = ~0ull;
+    /* ids from here on are the adapters' own (throw-away maps): a caller's id must be smaller */
+    static constexpr std::uint64_t kReservedIds = 1ull << 62;
     const std::uint16_t* mValues = nullptr;   /* row-major rows*cols */
     int mRows = 0, mCols = 0;
     double mResolution = 0.0;
     double mPosOffsetX = 0.0, mPosOffsetY = 0.0;
     std::uint64_t mId = kInvalidId;
+    /* A map with an id is uploaded once and then read from the device (the
+     * reference caches by LocalMapId because finished local maps never change,
+     * loop_detector_branch_bound.hpp:98). A caller that passes a map which is
+     * still growing under an id bumps mRevision whenever its cells change: the
+     * adapters upload again when the revision differs from the one they hold. */
+    std::uint64_t mRevision = 0;
 };
 
 /* What a matcher reads of Sensor::ScanData<double>
@@ -113,6 +121,9 @@ using CostCallback = void (*)(const ScanMatchingQuery&, const RobotPose2D<double
                               double*);
 
 namespace detail {
+/* which revision of which map id a context holds */
+using RevisionMap = std::map<std::uint64_t, std::uint64_t>;
+
 struct CtxDeleter {
     void operator()(csm_ctx* c) const { if (c) csm_destroy(c); }
 };
@@ -230,9 +241,18 @@ public:
         csm_ctx* ctx = this->mCtx.get();
         const GridMapView& g = q.mGridMap;
         const bool temporary = g.mId == GridMapView::kInvalidId;
-        const std::uint64_t id = temporary ? (1ull << 62) : g.mId;
-        if (temporary || !csm_has_grid(ctx, id))
+        if (!temporary && g.mId >= GridMapView::kReservedIds) {
+            std::fprintf(stderr, "Assertion failed: map id below 2^62 at %s:%d\n", __FILE__, __LINE__);
+            std::abort();
+        }
+        const std::uint64_t id = temporary ? GridMapView::kReservedIds : g.mId;
+        auto held = this->mRevisions.find(id);
+        /* mValues == nullptr: the map is already resident (built by a GridMapBuilderHIP on this context) */
+        if (g.mValues && (temporary || !csm_has_grid(ctx, id) || held == this->mRevisions.end() ||
+                          held->second != g.mRevision)) {
             CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, id, g.mValues, g.mRows, g.mCols));
+            this->mRevisions[id] = g.mRevision;
+        }
         csm_geometry geom { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
         const csm_scan scan = detail::ToScan(q.mScanData);
         csm_correlative_params prm {};
@@ -246,14 +266,32 @@ public:
                                  q.mMapLocalInitialPose.mTheta };
         csm_summary s {};
         CSM_ASSERT_OK(ctx, csm_correlative_match(ctx, id, &geom, &scan, init, &prm, &s));
-        if (temporary)
-            CSM_ASSERT_OK(ctx, csm_release_grid(ctx, id));
         ScanMatchingSummary out;
         detail::FillSummary(s, q.mMapLocalInitialPose, &out);
-        if (this->mCostFunc)
+        if (this->mCostFunc) {
             this->mCostFunc(q, out.mBestSensorPose, &out.mNormalizedCost, out.mEstimatedCovariance);
+        } else if (this->mDeviceCovarianceScale > 0.0) {
+            /* CostSquareError::Cost / ComputeCovariance at the best sensor pose on the device
+             * (scan_matcher_correlative.cpp:209-219) */
+            csm_loop_query cq {};
+            cq.map_id = id;
+            cq.geometry = geom;
+            cq.scan = scan;
+            csm_refine_result rr {};
+            CSM_ASSERT_OK(ctx, csm_cost_covariance_batch(ctx, &cq, 1, s.best_sensor_pose,
+                                                         this->mDeviceCovarianceScale, &rr));
+            out.mNormalizedCost = rr.normalized_cost;
+            for (int c = 0; c < 9; ++c)
+                out.mEstimatedCovariance[c] = rr.covariance[c];
+        }
+        if (temporary && g.mValues)
+            CSM_ASSERT_OK(ctx, csm_release_grid(ctx, id));
         return out;
     }
+
+    /* Cost and covariance from the device's CostSquareError instead of a host callback
+     * ("CovarianceScale", launcher_settings_default.json:11-13). */
+    void UseDeviceCostFunction(double covarianceScale = 1e4) { this->mDeviceCovarianceScale = covarianceScale; }
 
 private:
     ScanMatcherCorrelativeHIP(const std::string& name, int lowResolution, double rangeX,
@@ -267,6 +305,8 @@ private:
     const double mRangeX, mRangeY, mRangeTheta;
     const CostCallback mCostFunc;
     detail::CtxPtr mCtx;
+    detail::RevisionMap mRevisions;
+    double mDeviceCovarianceScale = 0.0;
 };
 
 /* ScanMatcherGridSearch (inc/mapping/scan_matcher_grid_search.hpp,
@@ -306,9 +346,17 @@ public:
         csm_ctx* ctx = this->mCtx.get();
         const GridMapView& g = q.mGridMap;
         const bool temporary = g.mId == GridMapView::kInvalidId;
-        const std::uint64_t id = temporary ? (1ull << 62) : g.mId;
-        if (temporary || !csm_has_grid(ctx, id))
+        if (!temporary && g.mId >= GridMapView::kReservedIds) {
+            std::fprintf(stderr, "Assertion failed: map id below 2^62 at %s:%d\n", __FILE__, __LINE__);
+            std::abort();
+        }
+        const std::uint64_t id = temporary ? GridMapView::kReservedIds + 1 : g.mId;
+        auto held = this->mRevisions.find(id);
+        if (g.mValues && (temporary || !csm_has_grid(ctx, id) || held == this->mRevisions.end() ||
+                          held->second != g.mRevision)) {
             CSM_ASSERT_OK(ctx, csm_upload_grid(ctx, id, g.mValues, g.mRows, g.mCols));
+            this->mRevisions[id] = g.mRevision;
+        }
         csm_geometry geom { g.mResolution, g.mPosOffsetX, g.mPosOffsetY };
         const csm_scan scan = detail::ToScan(q.mScanData);
         const csm_grid_search_params prm { this->mRangeX, this->mRangeY, this->mRangeTheta,
@@ -339,6 +387,7 @@ private:
     const double mStepX, mStepY, mStepTheta;
     const CostCallback mCostFunc;
     detail::CtxPtr mCtx;
+    detail::RevisionMap mRevisions;
 };
 
 /* inc/mapping/loop_detector.hpp:27-55, flattened to what the search reads:
