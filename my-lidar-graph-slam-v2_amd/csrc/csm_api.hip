@@ -89,6 +89,8 @@ struct csm_ctx {
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
+    void* pin = nullptr;          /* pinned staging of csm_upload_grid */
+    size_t pin_cap = 0;
     /* cost / refinement batches: device scans + job table, host staging */
     DevBuf c_scans, c_jobs, box_jobs;
     std::vector<csm::BoxJob> box_stage;
@@ -351,7 +353,6 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
  * (16-byte rows for the LDS-DMA pieces). Instantiated for these LS; a candidate
  * block may be any width cbx <= LS - 65. */
 const int kPairLS[] = { 86, 98, 118, 130, 150, 162, 182 };
-const int kPairR = 8;
 
 size_t pair_lds_bytes(int ls, int cby)
 {
@@ -364,9 +365,11 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
     if (const char* e = getenv("CSM_FINE_PAIRS"))       /* tuning / fallback knob */
         if (atoi(e) == 0)
             return false;
-    const int R = kPairR;
     double best = -1.0;
     const int max_cbx = kPairLS[sizeof(kPairLS) / sizeof(kPairLS[0]) - 1] - 65;
+    /* R = candidate rows per lane: 8, or 6 where that covers the rows with fewer
+     * multiply-adds per wave (52 rows: 9 groups x 6 instead of 7 x 8) */
+    for (int R : { 8, 6 })
     for (int ncbx = ceil_div(nx, max_cbx); ncbx <= ceil_div(nx, max_cbx) + 2; ++ncbx) {
         PassPlan p;
         p.nx = nx;
@@ -394,10 +397,11 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
         p.ncby = ceil_div(ny, g * R);
         g = ceil_div(ceil_div(ny, p.ncby), R);          /* balance the row blocks */
         p.groups = g;
-        /* per (block, tile): staging grows with the region, the gather does not
-         * depend on how many lanes are useful */
+        /* per (block, tile): the window copy grows with the region; the gather costs
+         * every wave R multiply-adds + ~6 other instructions per entry, however many
+         * of its lanes are useful; ~450 cycles of barriers and waits */
         const double cost = (double)p.ncbx * p.ncby *
-                            (0.01 * ((kTile + g * R) / 2 + 1) * p.lstride + 1260.0);
+                            (0.01 * ((kTile + g * R) / 2 + 1) * p.lstride + 46.0 * (R + 6) + 450.0);
         if (best < 0 || cost < best) {
             best = cost;
             *out = p;
@@ -564,15 +568,16 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
                            ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices, n_buf); \
     } while (0)
 
-#define PAIR_CASE(LS, CALL)                                                            \
-    if (pp.lstride == LS && pp.R == 8) {                                               \
+#define PAIR_CASE_R(LS, RR, CALL)                                                      \
+    if (pp.lstride == LS && pp.R == RR) {                                              \
         if (pp.weighted) {                                                             \
-            CALL(LS, 8, true);                                                         \
+            CALL(LS, RR, true);                                                        \
         } else {                                                                       \
-            CALL(LS, 8, false);                                                        \
+            CALL(LS, RR, false);                                                       \
         }                                                                              \
         launched = true;                                                               \
     }
+#define PAIR_CASE(LS, CALL) PAIR_CASE_R(LS, 8, CALL) PAIR_CASE_R(LS, 6, CALL)
 #ifdef CSM_FAST_BUILD
 #define PAIR_DISPATCH(CALL)                                                            \
     do {                                                                               \
@@ -644,11 +649,11 @@ int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n
      * a pair plan borrows the R = 8 instantiation of the plain kernel */
     PassPlan pp = plan;
     if (pp.pairs)
-        pp.lstride = 128;
+        pp.lstride = 128;        /* k_argmax<128, 6 | 8> exist */
     const dim3 grid(pp.ncb(), n_theta, 1);
     bool launched = false;
 #ifdef CSM_FAST_BUILD
-    ARGMAX_CASE(128, 8) ARGMAX_CASE(160, 7)
+    ARGMAX_CASE(128, 8) ARGMAX_CASE(128, 6) ARGMAX_CASE(160, 7)
 #else
     ARGMAX_CASE(96, 4) ARGMAX_CASE(96, 5) ARGMAX_CASE(96, 6) ARGMAX_CASE(96, 7) ARGMAX_CASE(96, 8)
     ARGMAX_CASE(128, 4) ARGMAX_CASE(128, 5) ARGMAX_CASE(128, 6) ARGMAX_CASE(128, 7) ARGMAX_CASE(128, 8)
@@ -1310,6 +1315,8 @@ int csm_destroy(csm_ctx* ctx)
             (void)hipFree(b->p);
     if (ctx->lut_dev)
         (void)hipFree(ctx->lut_dev);
+    if (ctx->pin)
+        (void)hipHostFree(ctx->pin);
     for (auto& kv : ctx->timers)
         for (auto& s : kv.second.spans) {
             (void)hipEventDestroy(s.a);
@@ -1382,10 +1389,26 @@ int csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense, int32_
     base.owned = true;
     base.cap = bytes;
     g.levels.push_back(base);
-    HIP_TRY(ctx, hipMemsetAsync(base.cells, 0, bytes, ctx->stream));
-    HIP_TRY(ctx, hipMemcpy2DAsync(base.cells, (size_t)g.pitch * 2, dense, (size_t)cols * 2,
-                                  (size_t)cols * 2, rows, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    /* GridMap::CopyValues' output goes through a pinned staging buffer of the context,
+     * already in the device layout (pitched rows, pad cells 0): one contiguous DMA, no
+     * device-side clearing, and the caller's buffer is free again when the call returns */
+    if (bytes > ctx->pin_cap) {
+        if (ctx->pin)
+            (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+        if (hipHostMalloc(&ctx->pin, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+        ctx->pin_cap = bytes + bytes / 4;
+    }
+    uint16_t* stage = reinterpret_cast<uint16_t*>(ctx->pin);
+    for (int r = 0; r < rows; ++r) {
+        std::memcpy(stage + (size_t)r * g.pitch, dense + (size_t)r * cols, (size_t)cols * 2);
+        if (g.pitch > cols)
+            std::memset(stage + (size_t)r * g.pitch + cols, 0, (size_t)(g.pitch - cols) * 2);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(base.cells, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      /* the staging buffer is reused by the next upload */
     return CSM_OK;
 }
 

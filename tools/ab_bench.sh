@@ -8,6 +8,6 @@ for rep in 1 2; do
     v="${spec%%:*}"; envs=""
     if [ "$spec" != "$v" ]; then envs="$(echo "${spec#*:}" | tr ',' ' ')"; fi
     env $envs CSM_HIP_LIB=$PWD/my-lidar-graph-slam-v2_amd/csrc/libcsm_hip_$v.so timeout -k 10 120 python bench.py --no-configs --no-cpu-baseline --steps 5 2>/dev/null \
-      | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$spec', round(d['roofline']['avg_launch_us'],1), 'us fine;', round(d['ms_per_step']*1e3/ (d['config']['scans_per_step']/64),1), 'us per chain;', d['config']['poses_found'])"
+      | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$spec', round(d['roofline']['avg_launch_us'],1), 'us fine;', {k: round(v,1) for k,v in d['roofline']['other_kernels_avg_us'].items()}, round(d['ms_per_step']*1e3/ (d['config']['scans_per_step']/64),1), 'us per chain;', d['config']['poses_found'])"
   done
 done
