@@ -23,6 +23,7 @@
 #include <string>
 #include <thread>
 #include <tuple>
+#include <atomic>
 #include <vector>
 
 #include "csm_kernels.hip"
@@ -91,6 +92,8 @@ struct csm_ctx {
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     void* pin = nullptr;          /* pinned staging of csm_upload_grid */
     size_t pin_cap = 0;
+    void* pin_scans = nullptr;    /* pinned staging of a batch's scans */
+    size_t pin_scans_cap = 0;
     /* cost / refinement batches: device scans + job table, host staging */
     DevBuf c_scans, c_jobs, box_jobs;
     std::vector<csm::BoxJob> box_stage;
@@ -220,6 +223,69 @@ bool scan_is_finite(const csm_scan* scan)
             return false;
     return std::isfinite(scan->relative_sensor_pose[0]) && std::isfinite(scan->relative_sensor_pose[1]) &&
            std::isfinite(scan->relative_sensor_pose[2]);
+}
+
+/* The same check and the scan's largest range in one pass over the beams (the
+ * batch entries need both for every query; x * 0 is NaN exactly when x is not
+ * finite, which keeps the loop free of branches). */
+bool scan_finite_max(const csm_scan* scan, double* max_range)
+{
+    double poison = 0.0, mx = scan->ranges[0];
+    for (int i = 0; i < scan->n_points; ++i) {
+        const double r = scan->ranges[i];
+        poison += r * 0.0 + scan->angles[i] * 0.0;
+        mx = r > mx ? r : mx;
+    }
+    *max_range = mx;
+    return poison == 0.0 && std::isfinite(scan->relative_sensor_pose[0]) &&
+           std::isfinite(scan->relative_sensor_pose[1]) && std::isfinite(scan->relative_sensor_pose[2]);
+}
+
+void search_step_from_max(double resolution, double max_range, double* step_x, double* step_y,
+                          double* step_theta)
+{
+    const double theta = resolution / max_range;
+    *step_x = resolution;
+    *step_y = resolution;
+    *step_theta = std::acos(1.0 - 0.5 * theta * theta);
+}
+
+/* Splits [0, n) over up to four host threads (the batch entries touch tens of
+ * megabytes of scan data before anything can be launched); fn(lo, hi) must not
+ * touch the context. */
+template <class F>
+void host_parallel_for(int n, int grain, F fn)
+{
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int nt = std::min(std::min(4, hw), n / std::max(1, grain));
+    if (nt <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> workers;
+    for (int w = 1; w < nt; ++w)
+        workers.emplace_back(fn, (int)((long)n * w / nt), (int)((long)n * (w + 1) / nt));
+    fn(0, (int)((long)n / nt));
+    for (auto& t : workers)
+        t.join();
+}
+
+/* scan_finite_max of every query; returns the first offending query or -1 */
+int scans_finite_max(const csm_loop_query* queries, int n_queries, double* max_range)
+{
+    std::atomic<int> bad(n_queries);
+    host_parallel_for(n_queries, 128, [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i) {
+            const csm_scan& sc = queries[i].scan;
+            if (!sc.angles || !sc.ranges || sc.n_points < 1 || !scan_finite_max(&sc, &max_range[i])) {
+                int cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+                }
+                return;
+            }
+        }
+    });
+    return bad.load() < n_queries ? bad.load() : -1;
 }
 
 /* Do enough beams share cells for merging to pay? A merged entry costs a
@@ -667,9 +733,11 @@ int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n
 }
 
 int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const PassPlan& pp,
-                       int n_theta_max, int n_slices)
+                       int n_theta_max, int n_slices, int theta_groups = 0)
 {
-    const dim3 grid(pp.ncb(), n_theta_max, n_jobs * n_slices);
+    /* theta_groups > 0: that many workgroups per (block, job) share the theta slices */
+    const dim3 grid(pp.ncb(), (theta_groups > 0 && !pp.pairs) ? std::min(theta_groups, n_theta_max) : n_theta_max,
+                    n_jobs * n_slices);
     if (pp.pairs) {
         if (n_slices != 1)
             return fail(ctx, CSM_EINVAL, "internal: pair kernel batches are not tile-split");
@@ -1317,6 +1385,8 @@ int csm_destroy(csm_ctx* ctx)
         (void)hipFree(ctx->lut_dev);
     if (ctx->pin)
         (void)hipHostFree(ctx->pin);
+    if (ctx->pin_scans)
+        (void)hipHostFree(ctx->pin_scans);
     for (auto& kv : ctx->timers)
         for (auto& s : kv.second.spans) {
             (void)hipEventDestroy(s.a);
@@ -1494,11 +1564,7 @@ int csm_host_search_step(double resolution, const double* ranges, int32_t n,
 {
     if (!ranges || n < 1)
         return CSM_EINVAL;
-    const double max_range = *std::max_element(ranges, ranges + n);
-    const double theta = resolution / max_range;
-    *step_x = resolution;
-    *step_y = resolution;
-    *step_theta = std::acos(1.0 - 0.5 * theta * theta);
+    search_step_from_max(resolution, *std::max_element(ranges, ranges + n), step_x, step_y, step_theta);
     return CSM_OK;
 }
 
@@ -2015,6 +2081,7 @@ struct BatchSpec {
     double score_thr = 0, known_thr = 0;
     const csm_bnb_params* bnb_params = nullptr;
     const csm_correlative_params* csm_params = nullptr;
+    const double* max_range = nullptr;   /* [n_queries] largest range of each query's scan */
 };
 
 /* csm_score_windows_dev: the windows and hit indices are given (device
@@ -2033,6 +2100,16 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
 {
     const int H = spec.H;
     const int nq = (int)idx.size();
+    const bool host_timing = getenv("CSM_HOST_TIMING") != nullptr;
+    auto tick = [&](const char* what) {
+        static thread_local std::chrono::steady_clock::time_point last;
+        const auto now = std::chrono::steady_clock::now();
+        if (host_timing && what)
+            fprintf(stderr, "[run_batch_group nq=%d] %-10s %8.3f ms\n", nq, what,
+                    std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
+    tick(nullptr);
     std::vector<BatchPrep> pp(nq);
     std::vector<csm_summary> scratch_out;
     if (resident) {                       /* no host summaries in this mode */
@@ -2061,8 +2138,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
             p.n = w.n_points;
         } else {
             csm_host_compound(q.initial_pose, q.scan.relative_sensor_pose, o.sensor_pose);
-            csm_host_search_step(q.geometry.resolution, q.scan.ranges, q.scan.n_points, &o.step_x,
-                                 &o.step_y, &o.step_theta);
+            search_step_from_max(q.geometry.resolution, spec.max_range[idx[k]], &o.step_x, &o.step_y,
+                                 &o.step_theta);
             o.win_x = p.win_x = csm_host_window(spec.range_x, o.step_x);
             o.win_y = p.win_y = csm_host_window(spec.range_y, o.step_y);
             o.win_theta = p.win_t = csm_host_window(spec.range_theta, o.step_theta);
@@ -2093,19 +2170,59 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
 
     /* scans go to the device as they are (angles, ranges); the projection runs
      * there with a per-entry certificate (k_project) */
+    /* Queries that share a scan (one query scan node against many local maps: the
+     * usual shape of a Detect() call) share its device copy. The staging buffer is
+     * pinned and owned by the context: no clearing, one DMA. */
     std::vector<size_t> scan_off(nq);
     size_t scan_total = 0;
-    for (int k = 0; k < nq; ++k) {
-        scan_off[k] = scan_total;
-        scan_total += 2 * (size_t)pp[k].n;
+    {
+        std::map<std::tuple<const double*, const double*, int>, size_t> seen;
+        for (int k = 0; k < nq; ++k) {
+            const csm_scan& sc = queries[idx[k]].scan;
+            auto key = std::make_tuple(sc.angles, sc.ranges, pp[k].n);
+            auto it = resident ? seen.end() : seen.find(key);
+            if (it != seen.end()) {
+                scan_off[k] = it->second;
+                continue;
+            }
+            scan_off[k] = scan_total;
+            if (!resident)
+                seen.emplace(key, scan_total);
+            scan_total += 2 * (size_t)pp[k].n;
+        }
     }
-    std::vector<double> scans(resident ? 0 : scan_total);
-    for (int k = 0; k < nq && !resident; ++k) {
-        const csm_loop_query& q = queries[idx[k]];
-        std::memcpy(scans.data() + scan_off[k], q.scan.angles, (size_t)pp[k].n * 8);
-        std::memcpy(scans.data() + scan_off[k] + pp[k].n, q.scan.ranges, (size_t)pp[k].n * 8);
+    double* scans = nullptr;
+    if (!resident) {
+        const size_t need = scan_total * 8;
+        if (need > ctx->pin_scans_cap) {
+            if (ctx->pin_scans)
+                (void)hipHostFree(ctx->pin_scans);
+            ctx->pin_scans = nullptr;
+            ctx->pin_scans_cap = 0;
+            if (hipHostMalloc(&ctx->pin_scans, need + need / 4 + 64, hipHostMallocDefault) != hipSuccess)
+                return fail(ctx, CSM_ENOMEM, "hipHostMalloc(%zu) failed", need);
+            ctx->pin_scans_cap = need + need / 4 + 64;
+        }
+        scans = reinterpret_cast<double*>(ctx->pin_scans);
+        size_t filled = 0;                  /* scans are laid out in first-use order */
+        std::vector<int> first_use;
+        for (int k = 0; k < nq; ++k) {
+            if (scan_off[k] != filled)
+                continue;                   /* a duplicate of an earlier query's scan */
+            first_use.push_back(k);
+            filled += 2 * (size_t)pp[k].n;
+        }
+        host_parallel_for((int)first_use.size(), 128, [&](int lo, int hi) {
+            for (int j = lo; j < hi; ++j) {
+                const int k = first_use[j];
+                const csm_loop_query& q = queries[idx[k]];
+                std::memcpy(scans + scan_off[k], q.scan.angles, (size_t)pp[k].n * 8);
+                std::memcpy(scans + scan_off[k] + pp[k].n, q.scan.ranges, (size_t)pp[k].n * 8);
+            }
+        });
     }
 
+    tick("setup");
     /* ---- launch geometry shared by the group ---- */
     std::vector<PassPlan> lp(H + 1);
     for (int h = 0; h <= H; ++h) {
@@ -2166,9 +2283,10 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_out + nq);
 
     if (!resident)
-        HIP_TRY(ctx, hipMemcpyAsync(d_scans, scans.data(), scan_total * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_scans, scans, scan_total * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, (size_t)nq * 4, ctx->stream));
 
+    tick("workspace");
     /* ---- job tables ---- */
     std::vector<ProjJob> ij(nq);
     std::vector<BinJob> bj(nq);
@@ -2357,6 +2475,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     for (int h = 0; h <= H; ++h)
         HIP_TRY(ctx, put(sj[h].data(), nq * sizeof(ScoreJob), &d_sj[h]));
 
+    tick("jobs");
     /* ---- launches ---- */
     if (!resident) {
         ScopedTimer tm(ctx, "project");
@@ -2390,7 +2509,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
                                  ? 1 : (int)std::min<long>(8, ceil_div(2048, (int)std::max<long>(1, blocks)));
         ScopedTimer tm(ctx, "score_coarse");
         if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[h]), nq, lp[h],
-                                     n_theta_max, n_slices)))
+                                     n_theta_max, n_slices, all_exit && nq >= 16 ? 4 : 0)))
             return rc;
     }
     {
@@ -2432,10 +2551,12 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
                            reinterpret_cast<const int32_t*>(d_idx), rec_dev, nq);
         HIP_TRY(ctx, hipGetLastError());
     }
+    tick("launch");
     std::vector<csm_result> res(nq);
     HIP_TRY(ctx, hipMemcpyAsync(res.data(), d_out, (size_t)nq * sizeof(csm_result),
                                 hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    tick("gpu wait");
 
     for (int k = 0; k < nq; ++k) {
         const csm_loop_query& q = queries[idx[k]];
@@ -2471,6 +2592,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         csm_host_move_backward(o.best_sensor_pose, q.scan.relative_sensor_pose, o.estimated_pose);
         o.candidates = (int64_t)pp[k].n_theta * nx * ny;
     }
+    tick("finish");
     return CSM_OK;
 }
 
@@ -2486,21 +2608,29 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
         return fail(ctx, CSM_EINVAL, "csm_bnb_match_batch: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int H = prm->node_height_max;
+    const bool host_timing = getenv("CSM_HOST_TIMING") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
     {
         int rc = begin_batch_records(ctx, n_queries);
         if (rc)
             return rc;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    if (host_timing)
+        fprintf(stderr, "[bnb batch] begin_records %8.3f ms\n", std::chrono::duration<double, std::milli>(t0 - tb0).count());
     /* pyramids: build and cache per map id, as mPrecompMaps does
      * (loop_detector_branch_bound.cpp:83-89) */
     std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
     std::vector<PendingBox> pending_levels;
-    for (int i = 0; i < n_queries; ++i) {
-        if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
+    std::vector<double> max_range(n_queries, 0.0);
+    {
+        const int i = scans_finite_max(queries, n_queries, max_range.data());
+        if (i >= 0 && (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1))
             return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
-        if (!scan_is_finite(&queries[i].scan))
+        if (i >= 0)
             return fail(ctx, CSM_EINVAL, "query %d: scan holds a non-finite range or angle", i);
+    }
+    for (int i = 0; i < n_queries; ++i) {
         DeviceGrid* g = find_grid(ctx, queries[i].map_id);
         if (!g)
             return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
@@ -2519,13 +2649,14 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
     }
     const auto t1 = std::chrono::steady_clock::now();
 
+    if (host_timing)
+        fprintf(stderr, "[bnb batch] levels        %8.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
     /* group queries by leaf-window shape */
     std::memset(out, 0, sizeof(csm_summary) * (size_t)n_queries);
     std::map<std::pair<int, int>, std::vector<int>> groups;
     for (int i = 0; i < n_queries; ++i) {
         double sx, sy, st;
-        csm_host_search_step(queries[i].geometry.resolution, queries[i].scan.ranges,
-                             queries[i].scan.n_points, &sx, &sy, &st);
+        search_step_from_max(queries[i].geometry.resolution, max_range[i], &sx, &sy, &st);
         const int big = 1 << H;
         const int nx = ceil_div(2 * csm_host_window(prm->range_x, sx) + 1, big) * big;
         const int ny = ceil_div(2 * csm_host_window(prm->range_y, sy) + 1, big) * big;
@@ -2534,6 +2665,7 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
     for (auto& kv : groups) {
         BatchSpec spec;
         spec.bnb = true;
+        spec.max_range = max_range.data();
         spec.H = H;
         for (int h = 0; h <= H; ++h)
             spec.stride[h] = 1 << h;
@@ -2544,6 +2676,9 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
         spec.score_thr = prm->score_threshold;
         spec.known_thr = prm->known_rate_threshold;
         spec.bnb_params = prm;
+        if (host_timing)
+            fprintf(stderr, "[bnb batch] grouping      %8.3f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         int rc = run_batch_group(ctx, queries, kv.second, levels, spec, out);
         if (rc)
             return rc;
@@ -2577,11 +2712,15 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<PendingBox> pending_levels;
     std::vector<std::vector<int>> levels(n_queries, std::vector<int>(H + 1, 0));
-    for (int i = 0; i < n_queries; ++i) {
-        if (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1)
+    std::vector<double> max_range(n_queries, 0.0);
+    {
+        const int i = scans_finite_max(queries, n_queries, max_range.data());
+        if (i >= 0 && (!queries[i].scan.angles || !queries[i].scan.ranges || queries[i].scan.n_points < 1))
             return fail(ctx, CSM_EINVAL, "query %d: empty scan", i);
-        if (!scan_is_finite(&queries[i].scan))
+        if (i >= 0)
             return fail(ctx, CSM_EINVAL, "query %d: scan holds a non-finite range or angle", i);
+    }
+    for (int i = 0; i < n_queries; ++i) {
         DeviceGrid* g = find_grid(ctx, queries[i].map_id);
         if (!g)
             return fail(ctx, CSM_ENOENT, "query %d: map %llu not resident", i,
@@ -2602,8 +2741,7 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
     std::map<std::pair<int, int>, std::vector<int>> groups;
     for (int i = 0; i < n_queries; ++i) {
         double sx, sy, st;
-        csm_host_search_step(queries[i].geometry.resolution, queries[i].scan.ranges,
-                             queries[i].scan.n_points, &sx, &sy, &st);
+        search_step_from_max(queries[i].geometry.resolution, max_range[i], &sx, &sy, &st);
         const int nx = ceil_div(2 * csm_host_window(prm->range_x, sx) + 1, L) * L;
         const int ny = ceil_div(2 * csm_host_window(prm->range_y, sy) + 1, L) * L;
         groups[{ nx, ny }].push_back(i);
@@ -2611,6 +2749,7 @@ int csm_correlative_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int
     for (auto& kv : groups) {
         BatchSpec spec;
         spec.bnb = false;
+        spec.max_range = max_range.data();
         spec.H = H;
         spec.stride[0] = 1;
         spec.stride[1] = L;
@@ -2969,3 +3108,18 @@ int csm_reset_kernel_timing(csm_ctx* ctx)
 
 #include "csm_cost_api.hip"
 #include "csm_group.hip"
+
+#ifdef CSM_BIN_TIMING
+/* tuning builds only (tools/build_variant.sh NAME -DCSM_BIN_TIMING): reads and clears k_bin's phase counters */
+extern "C" int csm_debug_bin_cycles(unsigned long long* out16)
+{
+    if (hipDeviceSynchronize() != hipSuccess)
+        return CSM_EIO;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(csm::g_bin_cycles), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return CSM_EIO;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(csm::g_bin_cycles), zero, sizeof(zero)) != hipSuccess)
+        return CSM_EIO;
+    return CSM_OK;
+}
+#endif

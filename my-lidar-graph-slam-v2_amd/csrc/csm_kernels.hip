@@ -73,6 +73,21 @@ __device__ __forceinline__ int cell_index(double pos, double off, double res)
     return (int)floor((pos - off) / res);
 }
 
+#ifdef CSM_BIN_TIMING
+/* tuning builds only: cycles per phase of k_bin, summed over workgroups (wave 0, lane 0) */
+__device__ unsigned long long g_bin_cycles[16];
+#define BIN_TICK(k)                                                                   \
+    do {                                                                              \
+        if (threadIdx.x == 0) {                                                       \
+            const unsigned long long now_ = __builtin_readcyclecounter();             \
+            atomicAdd(&g_bin_cycles[k], now_ - tick_);                                \
+            tick_ = now_;                                                             \
+        }                                                                             \
+    } while (0)
+#else
+#define BIN_TICK(k) do { } while (0)
+#endif
+
 /* ------------------------------------------------------------------ K0 */
 /* One workgroup (kBinBlock threads) per theta slice.
  *
@@ -120,6 +135,11 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const int32_t* row = job.hit_row + (size_t)t * n;
     const uint32_t hmask = (uint32_t)job.hash_size - 1u;
     const bool pairs = job.pair_mode != 0;
+#ifdef CSM_BIN_TIMING
+    unsigned long long tick_ = __builtin_readcyclecounter();
+    if (threadIdx.x == 0)
+        atomicAdd(&g_bin_cycles[15], 1ull);
+#endif
 
     if (job.zero_a)
         for (int i = tid; i < job.zero_words; i += kBinBlock) {
@@ -140,6 +160,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         hval[i] = 0;
     }
     __syncthreads();
+    BIN_TICK(0);
 
     /* Pass A: count the beams per (tile, cell) -- per (tile, row pair, column)
      * in pair mode -- and the bounding box of the hit cells per tile. */
@@ -175,6 +196,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     if (band)
         atomicOr(job.flags, kFlagBandTouch);
     __syncthreads();
+    BIN_TICK(1);
 
     /* the host decides per query whether merging pays (job.max_mult 1 = off) */
     const uint32_t max_mult = (uint32_t)job.max_mult;
@@ -207,6 +229,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             atomicAdd(&n_even[tile], ce - both);
     }
     __syncthreads();
+    BIN_TICK(2);
 
     /* exclusive scan of entry counts and of the records per tile */
     const int chunk = (ntile + kBinBlock - 1) / kBinBlock;
@@ -245,6 +268,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             job.n_tiles[t] = (int32_t)(bb2 + b);
     }
     __syncthreads();
+    BIN_TICK(3);
     uint32_t off = part[tid], slot_rec = part[kBinBlock + tid];
     TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
     for (int i = lo; i < hi; ++i) {
@@ -278,6 +302,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         n_even[i] = f + nb + nev;    /* odd-only cursor */
     }
     __syncthreads();
+    BIN_TICK(4);
 
     /* Pass C: the entries */
     uint32_t* out = job.sorted_pb + (size_t)t * n;
@@ -316,6 +341,10 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
                 out_rc[pos] = (mo << 28) | (me << 24) | (rb << 16) | cb;
         }
     }
+#ifdef CSM_BIN_TIMING
+    __syncthreads();
+    BIN_TICK(5);
+#endif
 }
 
 __global__ __launch_bounds__(kBinBlock) void k_bin(BinJob job)
@@ -505,11 +534,10 @@ __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S
  * otherwise every entry is one beam and the multiply is dropped. */
 template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int groups,
-                                           int slice, int n_slices, int n_buf)
+                                           int slice, int n_slices, int n_buf, int t)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
 
-    const int t = blockIdx.y;
     if (t >= job.n_theta)
         return;
     const int tid = threadIdx.x;
@@ -781,7 +809,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
 template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int groups, int n_buf)
 {
-    score_body<LSTRIDE, R, MODE, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, n_buf);
+    score_body<LSTRIDE, R, MODE, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, n_buf, blockIdx.y);
 }
 
 /* The arg-max pass after a tile-split launch (job.in_s set): same lane <->
@@ -790,16 +818,25 @@ __global__ __launch_bounds__(kBlock) void k_score(ScoreJob job, int cbx, int gro
 template <int LSTRIDE, int R>
 __global__ __launch_bounds__(kBlock) void k_argmax(ScoreJob job, int cbx, int groups)
 {
-    score_body<LSTRIDE, R, 0, false>(job, cbx, groups, 0, 1, 1);
+    score_body<LSTRIDE, R, 0, false>(job, cbx, groups, 0, 1, 1, blockIdx.y);
 }
 
-/* grid = (candidate blocks, theta slices, jobs * n_slices) */
+/* grid = (candidate blocks, theta slices or fewer, jobs * n_slices). A workgroup
+ * takes the slices blockIdx.y, blockIdx.y + gridDim.y, ...: the host folds the
+ * theta axis for levels that normally exit at once (skip_unless_band) -- 4,160
+ * workgroups that each allocate a region of LDS only to read one flag and leave
+ * took 47 us per 64-window launch. */
 template <int LSTRIDE, int R, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, int cbx, int groups,
                                                        int n_slices, int n_buf)
 {
-    score_body<LSTRIDE, R, MODE, WEIGHTED>(jobs[blockIdx.z / n_slices], cbx, groups,
-                                    blockIdx.z % n_slices, n_slices, n_buf);
+    const ScoreJob& job = jobs[blockIdx.z / n_slices];
+    if (job.skip_unless_band && !(*job.flags & kFlagBandTouch))
+        return;
+    for (int t = blockIdx.y; t < job.n_theta; t += gridDim.y) {
+        score_body<LSTRIDE, R, MODE, WEIGHTED>(job, cbx, groups, blockIdx.z % n_slices, n_slices, n_buf, t);
+        __syncthreads();
+    }
 }
 
 /* ------------------------------------------------------------------ K1, pair-row layout */

@@ -108,6 +108,23 @@ def test_bnb_negative_edge_band(gpu_ctx, oracle):
     _check_bnb(gpu_ctx, oracle, cases, 3, (0.3, 0.5), rng=(1.5, 1.5, 0.3))
 
 
+def test_bnb_twenty_queries_some_in_the_edge_band(gpu_ctx, oracle):
+    """>= 16 queries in one batch: the coarse levels are launched with the theta
+    axis folded (a workgroup loops over slices) and normally exit at once; the
+    low-edge queries here make those workgroups run their loop."""
+    cases = []
+    for i in range(20):
+        if i % 3 == 0:
+            cases.append(synth.csm_case(300 + i, n_beams=360, rows=256, cols=288, origin="low_edge", half_x=5.2,
+                                        half_y=4.4, init_error=(0.23, 0.19, 0.03)))
+        else:
+            cases.append(synth.csm_case(300 + i, n_beams=360, rows=256, cols=288, half_x=5.2, half_y=4.4,
+                                        init_error=(0.2, -0.1, 0.02)))
+    before = stats["band"]
+    _check_bnb(gpu_ctx, oracle, cases, 2, (0.3, 0.5), rng=(1.5, 1.5, 0.3), base_id=3300)
+    assert stats["band"] > before
+
+
 def test_bnb_cell_edge_aligned_projection(gpu_ctx, oracle):
     """Offsets, walls and poses on exact multiples of the resolution: hit points
     sit on cell edges, where sensor + x*step + r*cos and (sensor + r*cos) + x
@@ -164,3 +181,29 @@ def test_correlative_batch_mixes_fast_and_exact_paths(gpu_ctx, oracle):
             assert o["estimated_pose"] == lit["estimatedPose"]
         for i in range(len(cases)):
             gpu_ctx.release_grid(8000 + i)
+
+
+def test_correlative_batch_of_twenty_with_edge_band_queries(gpu_ctx, oracle):
+    """As above for csm_correlative_match_batch with a known-rate threshold of 0
+    (the coarse pass then only runs for queries whose beams reach the band)."""
+    cases = []
+    for i in range(20):
+        kw = dict(origin="low_edge", init_error=(0.23, 0.19, 0.03)) if i % 4 == 1 else dict(init_error=(0.1, 0.2, -0.02))
+        cases.append(synth.csm_case(340 + i, n_beams=360, rows=256, cols=288, half_x=5.2, half_y=4.4, **kw))
+    qs = []
+    for i, c in enumerate(cases):
+        gpu_ctx.upload_grid(8100 + i, c["grid"])
+        qs.append(dict(map_id=8100 + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+                       rel_pose=c["rel_pose"], init_pose=c["init_pose"]))
+    outs = gpu_ctx.correlative_match_batch(qs, 1.0, 1.0, math.radians(10), 4, 0.0, 0.0)
+    band = 0
+    for c, o in zip(cases, outs):
+        lit = oracle.csm(c, 1.0, 1.0, math.radians(10), 4, 0.0, 0.0)
+        raw = o["raw"]
+        assert o["pose_found"] == lit["found"], (raw, lit)
+        assert (raw["best_x"], raw["best_y"], raw["best_theta"]) == (lit["bestX"], lit["bestY"], lit["bestT"]), (raw, lit)
+        assert raw["score"] == lit["scoreMax"]
+        band += bool(raw["flags"] & L.FLAG_EDGE_BAND)
+    assert band > 0
+    for i in range(len(cases)):
+        gpu_ctx.release_grid(8100 + i)
