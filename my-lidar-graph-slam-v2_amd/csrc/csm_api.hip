@@ -32,6 +32,18 @@
 
 using namespace csm;
 
+#ifdef CSM_BIN_TIMING
+static unsigned long long* g_bin_debug = nullptr;
+static uint32_t* bin_debug_buffer()
+{
+    const size_t bytes = (size_t)kBinDebugRows * 128;
+    if (!g_bin_debug && (hipMalloc(reinterpret_cast<void**>(&g_bin_debug), bytes) != hipSuccess ||
+                         hipMemset(g_bin_debug, 0, bytes) != hipSuccess))
+        g_bin_debug = nullptr;
+    return reinterpret_cast<uint32_t*>(g_bin_debug);
+}
+#endif
+
 /* ------------------------------------------------------------------ ctx */
 
 namespace {
@@ -306,8 +318,7 @@ bool merging_pays(const double* angles, const double* ranges, int n, double res)
     return n >= 1.4 * cells;
 }
 
-/* k_bin's LDS: 8 per-tile arrays, 2 * kBinBlock scan words, hash keys + values
- * (load factor <= 2/3 when every beam lands on a cell of its own) */
+/* k_bin's hash table: load factor <= 2/3 when every beam lands on a cell of its own */
 int bin_hash_size(int n_points)
 {
     int h = 1024;
@@ -316,9 +327,11 @@ int bin_hash_size(int n_points)
     return h;
 }
 
+/* k_bin's LDS: three 64-bit words per tile, the hash table
+ * (keys, beam counts) and the list of occupied slots (16 bits each, a segment per wave) */
 size_t bin_lds_bytes(int tiles, int n_points)
 {
-    return ((size_t)8 * tiles + 2 * kBinBlock + 2 * (size_t)bin_hash_size(n_points)) * 4;
+    return ((size_t)6 * ((tiles + 1) & ~1) + 2 * (size_t)bin_hash_size(n_points)) * 4 + 2 * (size_t)n_points + 16;
 }
 
 
@@ -2355,6 +2368,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
         B.pair_mode = lp[0].pairs ? 1 : 0;
+#ifdef CSM_BIN_TIMING
+        B.tuning_counters = bin_debug_buffer();
+#endif
         B.frame_shift = lp[0].pairs ? ((ny - 1) & 1) : 0;
         B.n_band = H;
         for (int h = 1; h <= H; ++h) {
@@ -3113,13 +3129,24 @@ int csm_reset_kernel_timing(csm_ctx* ctx)
 /* tuning builds only (tools/build_variant.sh NAME -DCSM_BIN_TIMING): reads and clears k_bin's phase counters */
 extern "C" int csm_debug_bin_cycles(unsigned long long* out16)
 {
-    if (hipDeviceSynchronize() != hipSuccess)
+    /* out16[0..5]: cycles per phase (8..11: parts of pass A) summed over the workgroups of the LAST launch
+     * pattern (rows are overwritten by every launch), out16[15]: workgroups */
+    if (!g_bin_debug)
+        return CSM_ENOENT;
+    std::vector<unsigned long long> rows((size_t)kBinDebugRows * 16);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(rows.data(), g_bin_debug, rows.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
         return CSM_EIO;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(csm::g_bin_cycles), 16 * sizeof(unsigned long long)) != hipSuccess)
-        return CSM_EIO;
-    unsigned long long zero[16] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(csm::g_bin_cycles), zero, sizeof(zero)) != hipSuccess)
-        return CSM_EIO;
+    for (int k = 0; k < 16; ++k)
+        out16[k] = 0;
+    for (int r = 0; r < kBinDebugRows; ++r) {
+        if (!rows[(size_t)r * 16 + 7])
+            continue;
+        for (int k = 0; k < 12; ++k)
+            if (k != 7)
+                out16[k] += rows[(size_t)r * 16 + k];
+        out16[15] += 1;
+    }
     return CSM_OK;
 }
 #endif

@@ -60,9 +60,9 @@ struct BinJob {
     TileRec*  tiles;           /* [n_theta][max_tiles] */
     int32_t*  n_tiles;         /* [n_theta] */
     uint32_t* flags;           /* [1] CSM_FLAG_* accumulated with atomicOr */
-    uint32_t* zero_a;          /* optional: [n_theta][zero_words] arrays this kernel clears */
-    uint32_t* zero_b;          /*   (the coarse level's atomic accumulators)                */
-    int32_t   zero_words;
+    uint32_t* reserved_ptr;    /* unused (round 1 cleared the coarse accumulators here) */
+    uint32_t* tuning_counters; /* CSM_BIN_TIMING builds: per-workgroup phase cycles; else null */
+    int32_t   reserved_words;
     int32_t n_theta, n_points, max_tiles;
     int32_t rows, cols;
     int32_t x_lo, y_lo;        /* most negative candidate offset */

@@ -74,18 +74,27 @@ __device__ __forceinline__ int cell_index(double pos, double off, double res)
 }
 
 #ifdef CSM_BIN_TIMING
-/* tuning builds only: cycles per phase of k_bin, summed over workgroups (wave 0, lane 0) */
-__device__ unsigned long long g_bin_cycles[16];
+/* tuning builds only: cycles per phase of k_bin, one row of 8 counters per workgroup
+ * (thread 0, plain stores); the host points BinJob.tuning_counters at
+ * kBinDebugRows rows */
+constexpr int kBinDebugRows = 65536;
 #define BIN_TICK(k)                                                                   \
     do {                                                                              \
-        if (threadIdx.x == 0) {                                                       \
+        if (threadIdx.x == 0 && job.tuning_counters) {                                         \
             const unsigned long long now_ = __builtin_readcyclecounter();             \
-            atomicAdd(&g_bin_cycles[k], now_ - tick_);                                \
+            reinterpret_cast<unsigned long long*>(job.tuning_counters)[dbg_row_ * 16 + (k)] = now_ - tick_; \
             tick_ = now_;                                                             \
         }                                                                             \
     } while (0)
+#define BIN_SUB(k)                                                                    \
+    do {                                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter();                 \
+        sub_[k] += now_ - subt_;                                                      \
+        subt_ = now_;                                                                 \
+    } while (0)
 #else
 #define BIN_TICK(k) do { } while (0)
+#define BIN_SUB(k) do { } while (0)
 #endif
 
 /* ------------------------------------------------------------------ K0 */
@@ -110,26 +119,41 @@ __device__ unsigned long long g_bin_cycles[16];
  * mode r0 is rounded down to an even row of the tile frame, and the frame is
  * shifted by BinJob.frame_shift so that an even frame row + any candidate row
  * offset of the fine kernel's lanes is an even GRID row (the pair-row copy of
- * the grid pairs rows by their grid parity). */
+ * the grid pairs rows by their grid parity).
+ *
+ * How (round 2, 192 -> 92 us per 64-window launch of 7,744 slices): the kernel is
+ * bound by instruction issue and LDS round trips, not by bandwidth -- LDS atomics
+ * themselves run at 15-24 lanes per clock and CU (tools/micro/lds_atomic_bench.hip).
+ * So: runs of neighbouring lanes with one key are inserted once with the run's
+ * beam counts; the probes of all iterations of a thread travel together, one LDS
+ * round trip per probe step; the lanes that claim an empty slot record it in a
+ * per-wave list (no shared counter) and the later passes walk the distinct cells,
+ * not the table; a tile's three class counts share one 64-bit word and its
+ * bounding box is two 64-bit bit masks (3 atomics per cell, were 7); the cursor
+ * of pass C is one returning 64-bit add; the edge-band test is skipped by whole
+ * waves away from the map's low edges. */
 __device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
-    extern __shared__ uint32_t sm_bin[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm_bin[];
     const int ntile = job.tiles_x * job.tiles_y;
-    uint32_t* hist = sm_bin;            /* [ntile] entry counts, later the "both" cursor */
-    uint32_t* first = sm_bin + ntile;   /* [ntile] start offsets */
-    uint32_t* bb_rmin = first + ntile;  /* [ntile] beam bounding box inside the tile */
-    uint32_t* bb_rmax = bb_rmin + ntile;
-    uint32_t* bb_cmin = bb_rmax + ntile;
-    uint32_t* bb_cmax = bb_cmin + ntile;
-    uint32_t* n_both = bb_cmax + ntile; /* [ntile] class counts, later cursors */
-    uint32_t* n_even = n_both + ntile;
-    uint32_t* part = n_even + ntile;    /* [2 * kBinBlock] */
-    uint32_t* hkey = part + 2 * kBinBlock;   /* [hash_size] (tile, cell) + 1, 0 = empty */
+    /* per tile: entry counts (later the cursors) of the three classes, 21 bits each,
+     * in one 64-bit word -- total | both << 21 | even-only << 42 -- and the hit rows /
+     * columns of the tile as bit masks (bounding box = lowest / highest set bit): three
+     * 64-bit LDS atomics per distinct cell where seven 32-bit ones were needed */
+    const int ntp = (ntile + 1) & ~1;    /* keeps the hash table 16-byte aligned */
+    unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(sm_bin);   /* [ntp] */
+    unsigned long long* rowmask = cnt64 + ntp;                                    /* [ntp] */
+    unsigned long long* colmask = rowmask + ntp;                                  /* [ntp] */
+    uint32_t* hkey = reinterpret_cast<uint32_t*>(colmask + ntp);   /* [hash_size] (tile, cell) + 1, 0 = empty */
     uint32_t* hval = hkey + job.hash_size;   /* [hash_size] beams on that cell: even row | odd row << 16 */
+    /* occupied slots (< 32768), [n_points]: a segment per wave */
+    uint16_t* list = reinterpret_cast<uint16_t*>(hval + job.hash_size);
+    __shared__ uint32_t seg_n[kBinBlock / 64];   /* cells claimed by each wave */
     const int t = blockIdx.x;
     if (t >= job.n_theta)
         return;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int n = job.n_points;
     const int32_t* col = job.hit_col + (size_t)t * n;
     const int32_t* row = job.hit_row + (size_t)t * n;
@@ -137,96 +161,204 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     const bool pairs = job.pair_mode != 0;
 #ifdef CSM_BIN_TIMING
     unsigned long long tick_ = __builtin_readcyclecounter();
-    if (threadIdx.x == 0)
-        atomicAdd(&g_bin_cycles[15], 1ull);
+    const size_t dbg_row_ = min((size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)kBinDebugRows - 1);
+    if (threadIdx.x == 0 && job.tuning_counters)
+        reinterpret_cast<unsigned long long*>(job.tuning_counters)[dbg_row_ * 16 + 7] = 1ull;
 #endif
 
-    if (job.zero_a)
-        for (int i = tid; i < job.zero_words; i += kBinBlock) {
-            job.zero_a[(size_t)t * job.zero_words + i] = 0;
-            job.zero_b[(size_t)t * job.zero_words + i] = 0;
+    /* The kernel is bound by latencies, not by throughput: a thread's beams (i = tid,
+     * tid + kBinBlock, ...) are loaded kBinAhead iterations at a time so that pass A
+     * waits for memory once per chunk (one load per iteration, even prefetched one
+     * iteration ahead, was 58 % of the kernel); the first chunk is in flight while
+     * the tables are cleared. */
+    constexpr int kBinAhead = 6;
+    int rv[kBinAhead], cv[kBinAhead];
+#pragma unroll
+    for (int u = 0; u < kBinAhead; ++u) {
+        const int i = u * kBinBlock + tid;
+        rv[u] = cv[u] = 0;
+        if (i < n) {
+            rv[u] = row[i];
+            cv[u] = col[i];
         }
-    for (int i = tid; i < ntile; i += kBinBlock) {
-        hist[i] = 0;
-        n_both[i] = 0;
-        n_even[i] = 0;
-        bb_rmin[i] = kTile;
-        bb_cmin[i] = kTile;
-        bb_rmax[i] = 0;
-        bb_cmax[i] = 0;
     }
-    for (int i = tid; i < job.hash_size; i += kBinBlock) {
-        hkey[i] = 0;
-        hval[i] = 0;
+    for (int i = tid; i < 3 * ntp; i += kBinBlock)
+        cnt64[i] = 0ull;
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(hkey);      /* hkey and hval are contiguous */
+        for (int i = tid; i < job.hash_size / 2; i += kBinBlock)
+            h4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
     BIN_TICK(0);
 
-    /* Pass A: count the beams per (tile, cell) -- per (tile, row pair, column)
-     * in pair mode -- and the bounding box of the hit cells per tile. */
+    /* Pass A: count the beams per (tile, cell) -- per (tile, row pair, column) in pair
+     * mode. Neighbouring beams are neighbouring lanes and mostly land on the same or
+     * the next cell: a run of lanes with one key is inserted once, by its first lane,
+     * with the run's beam counts (same-address LDS atomics of a wave serialise). The
+     * lane that claims an empty slot appends it to `list`: passes B and C walk the
+     * distinct cells, not the table. */
     const int r_max = job.rows - 1 - job.y_lo;
     const int c_max = job.cols - 1 - job.x_lo;
     bool band = false;
     const int fs = job.frame_shift;          /* 0 / 1: see BinJob */
-    for (int i = tid; i < n; i += kBinBlock) {
-        const int r = row[i], c = col[i];
-        const int rr = r + job.y_hi + fs, cc = c + job.x_hi;
-        if (rr >= fs && r <= r_max && cc >= 0 && c <= c_max) {
-            const int tile = (rr / kTile) * job.tiles_x + cc / kTile;
-            const uint32_t rb = (uint32_t)(rr % kTile), cb = (uint32_t)(cc % kTile);
-            const uint32_t rkey = pairs ? rb >> 1 : rb;
-            const uint32_t key = (((uint32_t)tile << 12) | (rkey << 6) | cb) + 1u;
-            uint32_t slot = (key * 2654435761u) >> 12 & hmask;
-            while (true) {
-                const uint32_t old = atomicCAS(&hkey[slot], 0u, key);
-                if (old == 0u || old == key) {
-                    atomicAdd(&hval[slot], (pairs && (rb & 1u)) ? 0x10000u : 1u);
-                    break;
+    const int x_hi = job.x_hi, y_hi = job.y_hi, x_lo = job.x_lo, y_lo = job.y_lo;
+    const int tiles_x = job.tiles_x;
+    const int n_band = job.n_band;
+    const int n_iter = (n + kBinBlock - 1) / kBinBlock;
+#ifdef CSM_BIN_TIMING
+    unsigned long long sub_[4] = { 0, 0, 0, 0 }, subt_ = 0;
+#endif
+    /* edge-band test of one coordinate, division-free for the beams that cannot be in
+     * the band (all but those within one window of the map's low edge): band_hit() */
+    auto in_band = [&](int u, int w, int span, int known_lo) {
+        if (u > 0 || u <= -span)             /* k0 = floor(-u / w) outside [0, nk) */
+            return false;
+        const int m = (-u) % w;              /* v = -m */
+        return m != 0 && w - 1 - m >= known_lo;
+    };
+    const int known_r0 = job.known_r0, known_c0 = job.known_c0;
+    const int wave = tid >> 6;
+    /* a wave can claim one slot per beam it handles (i = it * kBinBlock + wave * 64 + lane):
+     * its segment of the list starts after the beams of the waves before it */
+    auto seg_base = [&](int w) { return (n / kBinBlock) * 64 * w + min(n % kBinBlock, 64 * w); };
+    uint16_t* my_list = list + seg_base(wave);
+    uint32_t my_count = 0;                   /* wave-uniform */
+    for (int it0 = 0; it0 < n_iter; it0 += kBinAhead) {
+        if (it0) {
+#pragma unroll
+            for (int u = 0; u < kBinAhead; ++u) {
+                const int i = (it0 + u) * kBinBlock + tid;
+                if (i < n) {
+                    rv[u] = row[i];
+                    cv[u] = col[i];
                 }
-                slot = (slot + 1u) & hmask;
             }
         }
-        for (int b = 0; b < job.n_band; ++b) {
-            const int w = job.band_win[b];
-            if (band_hit(r + job.y_lo, w, job.band_ny[b], job.known_r0) ||
-                band_hit(c + job.x_lo, w, job.band_nx[b], job.known_c0))
-                band = true;
+#ifdef CSM_BIN_TIMING
+        subt_ = __builtin_readcyclecounter();
+#endif
+        /* keys, run heads and the beam counts of the runs */
+        uint32_t key[kBinAhead], slot[kBinAhead], beams[kBinAhead];
+        bool pend[kBinAhead], first[kBinAhead];
+#pragma unroll
+        for (int u = 0; u < kBinAhead; ++u) {
+            key[u] = 0xffffffffu;
+            slot[u] = beams[u] = 0;
+            pend[u] = first[u] = false;
+            if (it0 + u >= n_iter)          /* uniform */
+                continue;
+            const int i = (it0 + u) * kBinBlock + tid;
+            const int r = rv[u], c = cv[u];
+            const int rr = r + y_hi + fs, cc = c + x_hi;
+            const bool valid = i < n && rr >= fs && r <= r_max && cc >= 0 && c <= c_max;
+            bool odd = false;
+            if (valid) {               /* rr, cc >= 0 */
+                const uint32_t tile = ((uint32_t)rr / kTile) * (uint32_t)tiles_x + (uint32_t)cc / kTile;
+                const uint32_t rb = (uint32_t)rr % kTile, cb = (uint32_t)cc % kTile;
+                const uint32_t rkey = pairs ? rb >> 1 : rb;
+                key[u] = ((tile << 12) | (rkey << 6) | cb) + 1u;
+                odd = pairs && (rb & 1u);
+            }
+            const uint32_t prev = (uint32_t)__shfl_up((int)key[u], 1, 64);
+            const bool head = valid && (lane == 0 || key[u] != prev);
+            const unsigned long long hm = __ballot(head), vm = __ballot(valid), om = __ballot(odd);
+            /* the run ends before the next head or the next lane without a cell */
+            const unsigned long long above = (hm | ~vm) & ~((2ull << lane) - 1ull);
+            const int e = above ? __builtin_ctzll(above) : 64;
+            const unsigned long long run = (e == 64 ? ~0ull : (1ull << e) - 1ull) & ~((1ull << lane) - 1ull);
+            const uint32_t co = (uint32_t)__popcll(run & om), ce = (uint32_t)__popcll(run) - co;
+            beams[u] = ce | (co << 16);
+            slot[u] = (key[u] * 2654435761u) >> 12 & hmask;
+            pend[u] = head;
+            /* every band lies at candidate offsets u <= 0: whole waves of beams away from
+             * the map's low edges skip the test (and the scalar loads of its parameters) */
+            const bool near_low_edge = i < n && (r + y_lo <= 0 || c + x_lo <= 0);
+            if (__any(near_low_edge)) {
+                if (near_low_edge)
+                    for (int b = 0; b < n_band; ++b) {
+                        const int w = job.band_win[b];
+                        if (in_band(r + y_lo, w, job.band_ny[b] * w, known_r0) ||
+                            in_band(c + x_lo, w, job.band_nx[b] * w, known_c0))
+                            band = true;
+                    }
+            }
         }
+        BIN_SUB(0);
+        /* insertion: the probes of the chunk's iterations travel together, one LDS
+         * round trip per probe step instead of one per step and iteration */
+        bool any = true;
+        while (any) {
+            uint32_t old[kBinAhead];
+#pragma unroll
+            for (int u = 0; u < kBinAhead; ++u)
+                old[u] = pend[u] ? atomicCAS(&hkey[slot[u]], 0u, key[u]) : 0u;
+            any = false;
+#pragma unroll
+            for (int u = 0; u < kBinAhead; ++u)
+                if (pend[u]) {
+                    if (old[u] == 0u || old[u] == key[u]) {
+                        first[u] = old[u] == 0u;
+                        atomicAdd(&hval[slot[u]], beams[u]);
+                        pend[u] = false;
+                    } else {
+                        slot[u] = (slot[u] + 1u) & hmask;
+                        any = true;
+                    }
+                }
+            any = __any(any);
+        }
+        BIN_SUB(1);
+        /* the lanes that claimed an empty slot append it to the wave's segment of the list */
+#pragma unroll
+        for (int u = 0; u < kBinAhead; ++u) {
+            const unsigned long long fm = __ballot(first[u]);
+            if (first[u])
+                my_list[my_count + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint16_t)slot[u];
+            my_count += (uint32_t)__popcll(fm);
+        }
+        BIN_SUB(2);
     }
+    if (lane == 0)
+        seg_n[wave] = my_count;
     if (band)
         atomicOr(job.flags, kFlagBandTouch);
+#ifdef CSM_BIN_TIMING
+    if (threadIdx.x == 0 && job.tuning_counters)
+        for (int k = 0; k < 4; ++k)
+            reinterpret_cast<unsigned long long*>(job.tuning_counters)[dbg_row_ * 16 + 8 + k] = sub_[k];
+#endif
     __syncthreads();
     BIN_TICK(1);
 
     /* the host decides per query whether merging pays (job.max_mult 1 = off) */
     const uint32_t max_mult = (uint32_t)job.max_mult;
     auto chunks = [&](uint32_t beams) { return (beams + max_mult - 1u) / max_mult; };
+    static_assert(kBinBlock == 256, "four list segments");
+    const uint32_t seg1 = seg_n[0], seg2 = seg1 + seg_n[1], seg3 = seg2 + seg_n[2];
+    const int n_cells = (int)(seg3 + seg_n[3]);
+    auto cell_slot = [&](int e) {
+        const uint32_t ue = (uint32_t)e;
+        const uint32_t sg = (ue >= seg1) + (ue >= seg2) + (ue >= seg3);
+        const uint32_t first_of = sg == 0 ? 0u : sg == 1 ? seg1 : sg == 2 ? seg2 : seg3;
+        return (uint32_t)list[(uint32_t)seg_base((int)sg) + (ue - first_of)];
+    };
 
-    /* Pass B: entries per tile and class (a cell with more than max_mult beams is split) */
-    for (int sl = tid; sl < job.hash_size; sl += kBinBlock) {
-        const uint32_t key = hkey[sl];
-        if (!key)
-            continue;
-        const uint32_t ce = chunks(hval[sl] & 0xffffu), co = chunks(hval[sl] >> 16);
+    /* Pass B: entries per tile and class (a cell with more than max_mult beams is
+     * split) and the tile's bounding box, from the distinct cells */
+    for (int e = tid; e < n_cells; e += kBinBlock) {
+        const uint32_t sl = cell_slot(e);
+        const uint32_t k1 = hkey[sl] - 1u, hv = hval[sl];
+        const uint32_t ce = chunks(hv & 0xffffu), co = chunks(hv >> 16);
         const uint32_t both = min(ce, co);
-        const int tile = (int)((key - 1u) >> 12);
-        /* the tile's bounding box, from the distinct cells (here the lanes of a wave hit
-         * different tiles; in pass A neighbouring beams share a tile and the same-address
-         * LDS atomics of a whole wave serialised: 190 us per 64-window launch) */
-        {
-            const uint32_t rk = ((key - 1u) >> 6) & 63u, cbk = (key - 1u) & 63u;
-            const uint32_t rlo = pairs ? 2u * rk + (ce ? 0u : 1u) : rk;
-            const uint32_t rhi = pairs ? 2u * rk + (co ? 1u : 0u) : rk;
-            atomicMin(&bb_rmin[tile], rlo);
-            atomicMax(&bb_rmax[tile], rhi);
-            atomicMin(&bb_cmin[tile], cbk);
-            atomicMax(&bb_cmax[tile], cbk);
-        }
-        atomicAdd(&hist[tile], max(ce, co));
-        if (both)
-            atomicAdd(&n_both[tile], both);
-        if (ce > both)
-            atomicAdd(&n_even[tile], ce - both);
+        const int tile = (int)(k1 >> 12);
+        const uint32_t rk = (k1 >> 6) & 63u, cbk = k1 & 63u;
+        const uint32_t rlo = pairs ? 2u * rk + (ce ? 0u : 1u) : rk;
+        const uint32_t rhi = pairs ? 2u * rk + (co ? 1u : 0u) : rk;
+        atomicAdd(&cnt64[tile], (unsigned long long)max(ce, co) | ((unsigned long long)both << 21) |
+                                    ((unsigned long long)(ce - both) << 42));
+        atomicOr(&rowmask[tile], (1ull << rlo) | (1ull << rhi));
+        atomicOr(&colmask[tile], 1ull << cbk);
     }
     __syncthreads();
     BIN_TICK(2);
@@ -234,25 +366,25 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     /* exclusive scan of entry counts and of the records per tile */
     const int chunk = (ntile + kBinBlock - 1) / kBinBlock;
     const int lo = tid * chunk, hi = min(lo + chunk, ntile);
-    uint32_t cnt = 0, ne = 0;
+    uint32_t cnt = 0, ne = 0, excl_cnt, excl_rec;
     for (int i = lo; i < hi; ++i) {
-        cnt += hist[i];
-        ne += (hist[i] + kPbMax - 1) / kPbMax;
+        const uint32_t c = (uint32_t)cnt64[i] & 0x1fffffu;
+        cnt += c;
+        ne += (c + kPbMax - 1) / kPbMax;
     }
     {
         /* wave64 shuffles, then the wave totals */
         uint32_t a = cnt, b = ne;
-        const int ln = tid & 63;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
-            if (ln >= d) {
+            if (lane >= d) {
                 a += ua;
                 b += ub;
             }
         }
         __shared__ uint32_t wtot[2][kBinBlock / 64];
-        if (ln == 63) {
+        if (lane == 63) {
             wtot[0][tid >> 6] = a;
             wtot[1][tid >> 6] = b;
         }
@@ -262,44 +394,45 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             ba += wtot[0][w];
             bb2 += wtot[1][w];
         }
-        part[tid] = ba + a - cnt;
-        part[kBinBlock + tid] = bb2 + b - ne;
+        excl_cnt = ba + a - cnt;
+        excl_rec = bb2 + b - ne;
         if (tid == kBinBlock - 1)
             job.n_tiles[t] = (int32_t)(bb2 + b);
     }
-    __syncthreads();
     BIN_TICK(3);
-    uint32_t off = part[tid], slot_rec = part[kBinBlock + tid];
-    TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t c = hist[i];
-        const uint32_t nb = n_both[i], nev = n_even[i];
-        first[i] = off;
-        const int rmin = pairs ? (int)(bb_rmin[i] & ~1u) : (int)bb_rmin[i];
-        for (uint32_t done = 0; done < c; done += kPbMax) {
-            TileRec rec;
-            rec.r0 = (i / job.tiles_x) * kTile - job.y_hi - job.frame_shift + rmin;
-            rec.c0 = (i % job.tiles_x) * kTile - job.x_hi + (int)bb_cmin[i];
-            rec.start = off + done;
-            rec.count = min(c - done, (uint32_t)kPbMax);
-            rec.h = (int)bb_rmax[i] - rmin + 1;
-            rec.w = (int)(bb_cmax[i] - bb_cmin[i]) + 1;
-            /* class counts of this chunk: entries [done, done + count) of the tile's
-             * list [both | even only | odd only] */
-            const uint32_t end = done + rec.count;
-            rec.pad[0] = (int)(min(end, nb) - min(done, nb));
-            rec.pad[1] = (int)(min(end, nb + nev) - min(max(done, nb), nb + nev));
-            recs[slot_rec++] = rec;
+    /* the records; the tile's word becomes its three cursors: both | even only | odd only */
+    {
+        uint32_t off = excl_cnt, slot_rec = excl_rec;
+        TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
+        for (int i = lo; i < hi; ++i) {
+            const unsigned long long w = cnt64[i];
+            const uint32_t c = (uint32_t)w & 0x1fffffu;
+            if (!c)
+                continue;
+            const uint32_t nb = (uint32_t)(w >> 21) & 0x1fffffu, nev = (uint32_t)(w >> 42);
+            const unsigned long long rm = rowmask[i], cm = colmask[i];
+            const int rlo = __builtin_ctzll(rm), rhi = 63 - __builtin_clzll(rm);
+            const int clo = __builtin_ctzll(cm), chi = 63 - __builtin_clzll(cm);
+            const int rmin = pairs ? (rlo & ~1) : rlo;
+            for (uint32_t done = 0; done < c; done += kPbMax) {
+                TileRec rec;
+                rec.r0 = (i / tiles_x) * kTile - y_hi - fs + rmin;
+                rec.c0 = (i % tiles_x) * kTile - x_hi + clo;
+                rec.start = off + done;
+                rec.count = min(c - done, (uint32_t)kPbMax);
+                rec.h = rhi - rmin + 1;
+                rec.w = chi - clo + 1;
+                /* class counts of this chunk: entries [done, done + count) of the tile's
+                 * list [both | even only | odd only] */
+                const uint32_t end = done + rec.count;
+                rec.pad[0] = (int)(min(end, nb) - min(done, nb));
+                rec.pad[1] = (int)(min(end, nb + nev) - min(max(done, nb), nb + nev));
+                recs[slot_rec++] = rec;
+            }
+            cnt64[i] = (unsigned long long)off | ((unsigned long long)(off + nb) << 21) |
+                       ((unsigned long long)(off + nb + nev) << 42);
+            off += c;
         }
-        off += c;
-    }
-    __syncthreads();
-    /* cursors: both | even only | odd only */
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t f = first[i], nb = n_both[i], nev = n_even[i];
-        hist[i] = f;
-        n_both[i] = f + nb;          /* even-only cursor */
-        n_even[i] = f + nb + nev;    /* odd-only cursor */
     }
     __syncthreads();
     BIN_TICK(4);
@@ -307,25 +440,24 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     /* Pass C: the entries */
     uint32_t* out = job.sorted_pb + (size_t)t * n;
     uint32_t* out_rc = job.sorted_rc ? job.sorted_rc + (size_t)t * n : nullptr;
-    for (int sl = tid; sl < job.hash_size; sl += kBinBlock) {
-        const uint32_t key = hkey[sl];
-        if (!key)
-            continue;
-        const uint32_t k1 = key - 1u;
+    const uint32_t lstride = (uint32_t)job.lstride;
+    for (int e = tid; e < n_cells; e += kBinBlock) {
+        const uint32_t sl = cell_slot(e);
+        const uint32_t k1 = hkey[sl] - 1u, hv = hval[sl];
         const int tile = (int)(k1 >> 12);
-        const uint32_t rmin = pairs ? bb_rmin[tile] & ~1u : bb_rmin[tile];
+        const uint32_t rlo = (uint32_t)__builtin_ctzll(rowmask[tile]);
+        const uint32_t rmin = pairs ? rlo & ~1u : rlo;
         const uint32_t rkey = (k1 >> 6) & 63u;
         const uint32_t rb = (pairs ? rkey << 1 : rkey) - rmin;      /* even in pair mode */
-        const uint32_t cb = (k1 & 63u) - bb_cmin[tile];
-        uint32_t be = hval[sl] & 0xffffu, bo = hval[sl] >> 16;
+        const uint32_t cb = (k1 & 63u) - (uint32_t)__builtin_ctzll(colmask[tile]);
+        uint32_t be = hv & 0xffffu, bo = hv >> 16;
         const uint32_t ce = chunks(be), co = chunks(bo);
         const uint32_t both = min(ce, co);
-        uint32_t pos_b = both ? atomicAdd(&hist[tile], both) : 0u;
-        uint32_t pos_x = 0;
-        if (ce > both)
-            pos_x = atomicAdd(&n_both[tile], ce - both);
-        else if (co > both)
-            pos_x = atomicAdd(&n_even[tile], co - both);
+        const unsigned long long cur = atomicAdd(&cnt64[tile], (unsigned long long)both |
+                                                                   ((unsigned long long)(ce - both) << 21) |
+                                                                   ((unsigned long long)(co - both) << 42));
+        uint32_t pos_b = (uint32_t)cur & 0x1fffffu;
+        uint32_t pos_x = ce > both ? (uint32_t)(cur >> 21) & 0x1fffffu : (uint32_t)(cur >> 42);
         const uint32_t total = max(ce, co);
         for (uint32_t k = 0; k < total; ++k) {
             const uint32_t me = min(be, max_mult), mo = min(bo, max_mult);
@@ -333,10 +465,9 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
             bo -= mo;
             const uint32_t pos = (me && mo) ? pos_b++ : pos_x++;
             if (pairs)      /* byte offset of the slot (8 B) | beams << 19 | m_even << 24 | m_odd << 28 */
-                out[pos] = (mo << 28) | (me << 24) | ((me + mo) << 19) |
-                           (((rb >> 1) * (uint32_t)job.lstride + cb) << 3);
+                out[pos] = (mo << 28) | (me << 24) | ((me + mo) << 19) | (((rb >> 1) * lstride + cb) << 3);
             else
-                out[pos] = (me << 16) | (rb * (uint32_t)job.lstride + cb);
+                out[pos] = (me << 16) | (rb * lstride + cb);
             if (out_rc)
                 out_rc[pos] = (mo << 28) | (me << 24) | (rb << 16) | cb;
         }

@@ -8,6 +8,7 @@ import sys
 
 sys.path[:0] = [".", "my-lidar-graph-slam-v2_amd"]
 os.environ.setdefault("CSM_BENCH_SCANS", "256")
+import torch  # noqa: E402,F401  (first: its bundled HIP runtime must be the one the library binds)
 import bench  # noqa: E402
 from csm_hip import _lib  # noqa: E402
 
@@ -26,3 +27,5 @@ for k, nm in enumerate(names):
     print("%-24s %9.0f cycles per workgroup  %5.1f %%" % (nm, buf[k] / max(wgs, 1), 100.0 * buf[k] / max(tot, 1)),
           file=sys.stderr)
 print("total %.0f cycles per workgroup" % (tot / max(wgs, 1)), file=sys.stderr)
+for k, nm in enumerate(["A: key + ballots", "A: hash insert", "A: list append", "A: band test"]):
+    print("  %-22s %9.0f cycles per workgroup" % (nm, buf[8 + k] / max(wgs, 1)), file=sys.stderr)
