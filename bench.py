@@ -95,17 +95,18 @@ def cell_entries(col, row, rows, cols, x_lo, y_lo, x_hi, y_hi, max_mult=15):
     return total
 
 
-def pmc_traffic():
+def pmc_traffic(path=None):
     """HBM bytes per fine-kernel launch from the committed PMC passes (rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command,
     FETCH_SIZE doubled per the gfx950 note). A live bench run cannot collect
     counters itself, so this is a committed measurement, labelled as such;
     (None, None) when the file is absent."""
+    path = path or PMC_FILE
     try:
-        with open(PMC_FILE) as f:
+        with open(path) as f:
             d = json.load(f)
         src = "%s (committed; kernel %s, %s windows per launch, library %s)" % (
-            os.path.relpath(PMC_FILE, ROOT), d.get("kernel", "?"), d.get("windows_per_launch", "?"),
+            os.path.relpath(path, ROOT), d.get("kernel", "?"), d.get("windows_per_launch", "?"),
             d.get("library_version", "?"))
         return float(d["hbm_bytes_per_launch"]), src
     except (OSError, KeyError, ValueError):
@@ -179,7 +180,7 @@ def make_loop_queries(ctx, lo, hi):
 def loop_roofline(leaves, fine_ms, fine_n, entries_per_leaf_query=None):
     alg = 2.0 * N_BEAMS * leaves
     avg = fine_ms / max(1, fine_n) * 1e-3
-    d = {"bound": "lds", "kernel": "k_score_batch (leaf level)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
+    d = {"bound": "lds", "kernel": "k_score_pairs_batch (leaf level, all queries of the batch in one launch)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
          "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": None,
          "logical_hbm_gbs": alg / avg / 1e9 if avg > 0 else 0.0,
          "logical_hbm_frac": alg / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0}
@@ -389,14 +390,16 @@ def measure_config5(dev_index, runs=2):
                        -out["win_y"] + ny - 1)
     lds = 4.0 * ent / (2 * wt + 1) * cands
     ctx.close()
+    traffic, traffic_src = pmc_traffic(os.path.join(ROOT, "profiles", "r02_config5_pmc_traffic.json"))
     return {"workload": "configs[4]: exhaustive global CSM, 2000x2000@2.5cm, +-10 m/+-180 deg at 2.5 cm/0.25 deg, "
                         "1080 beams, L=4; host-inclusive csm_correlative_match (projection on device)",
             "value": cands / dt, "unit": "candidate poses/s", "ms_per_query": dt * 1e3, "runs": runs,
             "candidates": cands, "found": out["pose_found"], "upload_ms": t_up * 1e3,
-            "roofline": {"bound": "lds", "kernel": "k_score (fine level)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
+            "roofline": {"bound": "lds", "kernel": "k_score_pairs (fine level, one window)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
                          "achieved": lds / avg / 1e9 if avg > 0 else None,
                          "frac": lds / avg / 1e9 / LDS_PEAK_GBS if avg > 0 else None,
-                         "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": None,
+                         "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "logical_hbm_gbs": 2.0 * N_BEAMS * cands / avg / 1e9 if avg > 0 else None,
                          "logical_hbm_frac": 2.0 * N_BEAMS * cands / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else None}}
 
@@ -676,7 +679,7 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
             },
             "roofline": {
                 "bound": "lds",
-                "kernel": "k_score_batch (fine level, %d windows per launch)" % WINDOWS_PER_LAUNCH,
+                "kernel": "k_score_pairs_batch (fine level, %d windows per launch)" % WINDOWS_PER_LAUNCH,
                 "achieved": achieved,
                 "peak": LDS_PEAK_GBS,
                 "unit": "GB/s",
