@@ -225,6 +225,16 @@ double value_to_probability(unsigned v)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+/* k_project's grid.y: workgroups per (beam block, job) that share the theta slices --
+ * few (each pays two library calls per beam once), but enough workgroups to fill
+ * the chip and at most kProjSlices slices each */
+int proj_theta_groups(int n_theta, long blocks_xz)
+{
+    long g = std::min<long>(n_theta, std::max<long>(1, (1024 + blocks_xz - 1) / std::max<long>(1, blocks_xz)));
+    g = std::max<long>(g, ceil_div(n_theta, kProjSlices));
+    return (int)g;
+}
+
 /* A "no return" beam (inf / NaN range) has no hit point; the reference's scan
  * filters drop such beams before a matcher sees the scan. The library refuses
  * them instead of converting a non-finite coordinate to an int. */
@@ -1857,8 +1867,8 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     pj.res = geom->resolution;
     {
         ScopedTimer tm(ctx, "project");
-        hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), w.n_theta), dim3(kBlock), 0,
-                           ctx->stream, pj);
+        hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), proj_theta_groups(w.n_theta, ceil_div(n, kBlock))),
+                           dim3(kBlock), 0, ctx->stream, pj);
         HIP_TRY(ctx, hipGetLastError());
     }
     if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
@@ -2495,7 +2505,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     /* ---- launches ---- */
     if (!resident) {
         ScopedTimer tm(ctx, "project");
-        hipLaunchKernelGGL(k_project_batch, dim3(ceil_div(n_points_max, kBlock), n_theta_max, nq),
+        const int pb = ceil_div(n_points_max, kBlock);
+        hipLaunchKernelGGL(k_project_batch, dim3(pb, proj_theta_groups(n_theta_max, (long)pb * nq), nq),
                            dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ProjJob*>(d_ij));
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -3021,7 +3032,8 @@ int csm_project_scan(csm_ctx* ctx, const csm_geometry* geom, const double sensor
     pj.off_x = geom->offset_x;
     pj.off_y = geom->offset_y;
     pj.res = geom->resolution;
-    hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), n_theta), dim3(kBlock), 0, ctx->stream, pj);
+    hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), proj_theta_groups(n_theta, ceil_div(n, kBlock))),
+                       dim3(kBlock), 0, ctx->stream, pj);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t count = 0;
     HIP_TRY(ctx, hipMemcpyAsync(hit_col, col_dev, hn * 4, hipMemcpyDeviceToHost, ctx->stream));

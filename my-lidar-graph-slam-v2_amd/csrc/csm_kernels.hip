@@ -1756,81 +1756,113 @@ __global__ __launch_bounds__(256) void k_scatter_records(const csm_result* src, 
     d[2] = s[2];
 }
 
-/* Bound on |q_host - q_device| for q = (sensor + r*trig - off) / res, in
- * cells: 3 ulp between the two libms on the trig value, one rounding per
- * arithmetic step on either side; the caller multiplies by a safety factor. */
+/* Bound on |q_host - q_device| for q = (sensor + r*trig - off) / res, in cells.
+ * `trig_err`: absolute error of the device's cosine / sine against the host's
+ * cos(arg) / sin(arg) (see proj_body); then one rounding per arithmetic step on
+ * either side; the caller multiplies by a safety factor. */
 __device__ __forceinline__ double proj_err_bound(double r, double hit, double off, double res,
-                                                 double q)
+                                                 double q, double trig_err)
 {
-    return (fabs(r) * 8e-16 + (fabs(hit) + fabs(off)) * 4e-16) / res + fabs(q) * 4e-16;
+    return (fabs(r) * trig_err + (fabs(hit) + fabs(off)) * 4e-16) / res + fabs(q) * 4e-16;
 }
+
+/* grid = (beam blocks, theta groups, jobs): a thread owns one beam and walks the
+ * theta slices blockIdx.y, blockIdx.y + gridDim.y, ...
+ *
+ * The reference evaluates cos / sin of arg = (sensor.theta + stepTheta * t) + a_i
+ * for every slice and beam (scan_matcher_correlative.cpp:163-166, 277-297). Here
+ * a thread calls the library once, for B = sensor.theta + a_i, a workgroup once
+ * per slice for D = stepTheta * t, and the slice's values come from the addition
+ * theorems: 2 + 2/beams calls per beam and slice became 2/slices + 2/beams. The
+ * result is NOT the host's value bit for bit and does not have to be: an entry
+ * counts only if floor() cannot flip within the error bound (the certificate),
+ * everything else is recomputed on the host. Error of the cosine (sine alike):
+ *   |arg_host - (sensor.theta + D + a_i)| <= 1.5 ulp of the larger angle (the host
+ *   rounds theta_t and arg, the device rounds B)      -> 4e-16 * (|theta| + |D| + |a|)
+ *   device libm <= 3 ulp on each of cosB, sinB, cosD, sinD, two products, one sum
+ *                                                     -> 2.4e-15 */
+constexpr int kProjSlices = 256;     /* slices per workgroup (LDS table) */
 
 __device__ __forceinline__ void proj_body(const ProjJob& job)
 {
-    const int t = blockIdx.y;
-    if (t >= job.n_theta)
+    __shared__ double tab_c[kProjSlices], tab_s[kProjSlices];
+    const int n_local = (job.n_theta - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;   /* slices of this group */
+    if (n_local <= 0)
         return;
+    for (int k = threadIdx.x; k < n_local; k += kBlock) {
+        const int tt = ((int)blockIdx.y + k * (int)gridDim.y) - job.win_theta;
+        const double d = job.step_theta * tt;
+        tab_c[k] = cos(d);
+        tab_s[k] = sin(d);
+    }
+    __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= job.n_points)
         return;
-    /* scan_matcher_correlative.cpp:163-166: theta = sensor.theta + stepTheta * t */
-    const int tt = t - job.win_theta;
-    const double theta = job.sensor_theta + job.step_theta * tt;
-    const double arg = theta + job.angles[i];
+    const double a = job.angles[i];
     const double r = job.ranges[i];
-    const double rc = r * cos(arg);
-    const double rs = r * sin(arg);
-    const double hx = job.sensor_x + rc, hy = job.sensor_y + rs;
-    const double qx = (hx - job.off_x) / job.res, qy = (hy - job.off_y) / job.res;
-    const double fx = floor(qx), fy = floor(qy);
-    const double mx = 64.0 * proj_err_bound(r, hx, job.off_x, job.res, qx);
-    const double my = 64.0 * proj_err_bound(r, hy, job.off_y, job.res, qy);
-    const size_t idx = (size_t)t * job.n_points + i;
-    const int col = (int)fx, row = (int)fy;
-    job.hit_col[idx] = col;
-    job.hit_row[idx] = row;
-    bool uncertain = !(qx - fx > mx && qx - fx < 1.0 - mx && qy - fy > my && qy - fy < 1.0 - my);
-    if (job.check_nodes && !uncertain) {
-        /* appendNode's pose (scan_matcher_branch_bound.cpp:156-176):
-         * floor(((sensor + x*step) + r*trig - off) / res) must equal base + x for
-         * every node offset x. The search step IS the resolution
-         * (scan_matcher_branch_bound.cpp:293-312), so in exact arithmetic the
-         * node coordinate is q + x; every rounding on the way is bounded, hence
-         * one test per beam and axis certifies all offsets at once. Only beams
-         * within that (slightly wider) margin of a cell edge walk the offsets. */
-        const double xr = fmax(fabs((double)job.x_lo), fabs((double)(job.x_lo + job.nx - 1))) * job.step_x;
-        const double yr = fmax(fabs((double)job.y_lo), fabs((double)(job.y_lo + job.ny - 1))) * job.step_y;
-        const double wx = 64.0 * ((fabs(r) * 8e-16 + (fabs(hx) + xr + fabs(job.off_x)) * 8e-16) / job.res +
-                                  (fabs(qx) + xr / job.res) * 8e-16);
-        const double wy = 64.0 * ((fabs(r) * 8e-16 + (fabs(hy) + yr + fabs(job.off_y)) * 8e-16) / job.res +
-                                  (fabs(qy) + yr / job.res) * 8e-16);
-        const bool unit_step = job.step_x == job.res && job.step_y == job.res;
-        const bool sure_x = unit_step && qx - fx > wx && qx - fx < 1.0 - wx;
-        const bool sure_y = unit_step && qy - fy > wy && qy - fy < 1.0 - wy;
-        for (int xi = 0; xi < job.nx && !sure_x && !uncertain; ++xi) {
-            const int x = job.x_lo + xi;
-            const double h = (job.sensor_x + x * job.step_x) + rc;
-            const double q = (h - job.off_x) / job.res;
-            const double f = floor(q);
-            const double m = 64.0 * proj_err_bound(r, h, job.off_x, job.res, q);
-            uncertain = !((int)f == col + x && q - f > m && q - f < 1.0 - m);
+    const double bb = job.sensor_theta + a;
+    const double cb = cos(bb), sb = sin(bb);
+    const double ang = fabs(job.sensor_theta) + fabs(a);
+    /* branch and bound: the widest node offsets, once per beam */
+    const double xr = fmax(fabs((double)job.x_lo), fabs((double)(job.x_lo + job.nx - 1))) * job.step_x;
+    const double yr = fmax(fabs((double)job.y_lo), fabs((double)(job.y_lo + job.ny - 1))) * job.step_y;
+    const bool unit_step = job.step_x == job.res && job.step_y == job.res;
+    for (int k = 0; k < n_local; ++k) {
+        const int t = (int)blockIdx.y + k * (int)gridDim.y;
+        const double cd = tab_c[k], sd = tab_s[k];
+        const double trig_err = 2.4e-15 + 4e-16 * (ang + fabs(job.step_theta * (t - job.win_theta)));
+        const double rc = r * (cb * cd - sb * sd);
+        const double rs = r * (sb * cd + cb * sd);
+        const double hx = job.sensor_x + rc, hy = job.sensor_y + rs;
+        const double qx = (hx - job.off_x) / job.res, qy = (hy - job.off_y) / job.res;
+        const double fx = floor(qx), fy = floor(qy);
+        const double mx = 64.0 * proj_err_bound(r, hx, job.off_x, job.res, qx, trig_err);
+        const double my = 64.0 * proj_err_bound(r, hy, job.off_y, job.res, qy, trig_err);
+        const size_t idx = (size_t)t * job.n_points + i;
+        const int col = (int)fx, row = (int)fy;
+        job.hit_col[idx] = col;
+        job.hit_row[idx] = row;
+        bool uncertain = !(qx - fx > mx && qx - fx < 1.0 - mx && qy - fy > my && qy - fy < 1.0 - my);
+        if (job.check_nodes && !uncertain) {
+            /* appendNode's pose (scan_matcher_branch_bound.cpp:156-176):
+             * floor(((sensor + x*step) + r*trig - off) / res) must equal base + x for
+             * every node offset x. The search step IS the resolution
+             * (scan_matcher_branch_bound.cpp:293-312), so in exact arithmetic the
+             * node coordinate is q + x; every rounding on the way is bounded, hence
+             * one test per beam and axis certifies all offsets at once. Only beams
+             * within that (slightly wider) margin of a cell edge walk the offsets. */
+            const double wx = 64.0 * ((fabs(r) * trig_err + (fabs(hx) + xr + fabs(job.off_x)) * 8e-16) / job.res +
+                                      (fabs(qx) + xr / job.res) * 8e-16);
+            const double wy = 64.0 * ((fabs(r) * trig_err + (fabs(hy) + yr + fabs(job.off_y)) * 8e-16) / job.res +
+                                      (fabs(qy) + yr / job.res) * 8e-16);
+            const bool sure_x = unit_step && qx - fx > wx && qx - fx < 1.0 - wx;
+            const bool sure_y = unit_step && qy - fy > wy && qy - fy < 1.0 - wy;
+            for (int xi = 0; xi < job.nx && !sure_x && !uncertain; ++xi) {
+                const int x = job.x_lo + xi;
+                const double h = (job.sensor_x + x * job.step_x) + rc;
+                const double q = (h - job.off_x) / job.res;
+                const double f = floor(q);
+                const double m = 64.0 * proj_err_bound(r, h, job.off_x, job.res, q, trig_err);
+                uncertain = !((int)f == col + x && q - f > m && q - f < 1.0 - m);
+            }
+            for (int yi = 0; yi < job.ny && !sure_y && !uncertain; ++yi) {
+                const int y = job.y_lo + yi;
+                const double h = (job.sensor_y + y * job.step_y) + rs;
+                const double q = (h - job.off_y) / job.res;
+                const double f = floor(q);
+                const double m = 64.0 * proj_err_bound(r, h, job.off_y, job.res, q, trig_err);
+                uncertain = !((int)f == row + y && q - f > m && q - f < 1.0 - m);
+            }
         }
-        for (int yi = 0; yi < job.ny && !sure_y && !uncertain; ++yi) {
-            const int y = job.y_lo + yi;
-            const double h = (job.sensor_y + y * job.step_y) + rs;
-            const double q = (h - job.off_y) / job.res;
-            const double f = floor(q);
-            const double m = 64.0 * proj_err_bound(r, h, job.off_y, job.res, q);
-            uncertain = !((int)f == row + y && q - f > m && q - f < 1.0 - m);
-        }
-    }
-    if (uncertain) {
-        if (job.check_nodes || job.flag_uncertain) {
-            atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
-        } else {
-            const uint32_t pos = atomicAdd(job.unc_count, 1u);
-            if (pos < job.unc_cap)
-                job.unc_list[pos] = (uint32_t)idx;
+        if (uncertain) {
+            if (job.check_nodes || job.flag_uncertain) {
+                atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
+            } else {
+                const uint32_t pos = atomicAdd(job.unc_count, 1u);
+                if (pos < job.unc_cap)
+                    job.unc_list[pos] = (uint32_t)idx;
+            }
         }
     }
 }

@@ -30,7 +30,7 @@ namespace csm {
 __device__ __forceinline__ bool map_certified(double r, double h, double off, double res)
 {
     const double q = (h - off) / res;
-    const double m = 64.0 * proj_err_bound(r, h, off, res, q) +
+    const double m = 64.0 * proj_err_bound(r, h, off, res, q, 8e-16) +    /* 3 ulp between the two libms */
                      64.0 * 2.3e-16 * (fabs(h) + fabs(off) + 1.0e3) / res;
     const double frac = q - floor(q);
     return frac > m && frac < 1.0 - m;
