@@ -567,41 +567,67 @@ __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S
     unsigned long long bkey = 0, brank = ~0ull;
     uint32_t bcnt = 0;
     bool bound_broken = false;
-    const bool band_touch =
-        (job.block_best || job.tie_list) && job.n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
-    if (lane_on && xi < job.nx) {
+    /* every job field the candidate loop needs, read once (`job` lives in global
+     * memory and the stores below may alias it as far as the compiler knows) */
+    BlockBest* const block_best = job.block_best;
+    unsigned long long* const tie_list = job.tie_list;
+    uint32_t* const dump_s = job.dump_s;
+    uint16_t* const dump_k = job.dump_k;
+    uint32_t* const acc_s = job.acc_s;
+    uint32_t* const acc_k = job.acc_k;
+    const int nx = job.nx, ny = job.ny, n_elig = job.n_elig, min_known = job.min_known;
+    const bool acc_x_major = job.acc_x_major != 0;
+    const bool check_known = job.check_own_known != 0;
+    const bool use_elig = !job.elig_only_if_band || (qflags & kFlagBandTouch);
+    const bool band_touch = (block_best || tie_list) && n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
+    const unsigned long long collect_key = tie_list ? *job.collect_key : 0ull;
+    if (lane_on && xi < nx) {
+        /* the traversal rank of candidate (t, xi, yi): the divisions by the coarse
+         * stride are done once per lane, the lane's R consecutive rows step the
+         * quotient and remainder (eight candidates x four integer divisions by a
+         * run-time divisor were a seventh of the kernel's vector instructions) */
+        const int L = max(job.rank_l, 1);
+        const int nxc = nx / L, nyc = ny / L;
+        const int xq = xi / L, xm = xi - xq * L;
+        const int y_first = by * cby + g * R;
+        int yq = y_first / L, ym = y_first - yq * L - 1;
+        const unsigned long long rank_x = ((unsigned long long)t * nxc + xq) * nyc;
+        int best_yq = -1, best_ym = 0;      /* the lane's first best row: ranks grow with the row */
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int yi = by * cby + g * R + r;
-            if (yi >= job.ny)
+            const int yi = y_first + r;
+            if (++ym == L) {
+                ym = 0;
+                ++yq;
+            }
+            if (yi >= ny)
                 continue;
-            const size_t ci = ((size_t)t * job.nx + xi) * job.ny + yi;
-            if (job.dump_s)
-                job.dump_s[ci] = S[r];
-            if (job.dump_k)
-                job.dump_k[ci] = (uint16_t)K[r];
-            if (job.acc_s) {
+            const size_t ci = ((size_t)t * nx + xi) * ny + yi;
+            if (dump_s)
+                dump_s[ci] = S[r];
+            if (dump_k)
+                dump_k[ci] = (uint16_t)K[r];
+            if (acc_s) {
                 /* tile-split launch: slices add their partial integer sums.
                  * acc_x_major: consecutive lanes (dx) hit consecutive words */
-                const size_t ai = job.acc_x_major ? ((size_t)t * job.ny + yi) * job.nx + xi : ci;
+                const size_t ai = acc_x_major ? ((size_t)t * ny + yi) * nx + xi : ci;
                 if (S[r])
-                    atomicAdd(&job.acc_s[ai], S[r]);
+                    atomicAdd(&acc_s[ai], S[r]);
                 if (K[r])
-                    atomicAdd(&job.acc_k[ai], K[r]);
+                    atomicAdd(&acc_k[ai], K[r]);
             }
-            if (!job.block_best && !job.tie_list)
+            if (!block_best && !tie_list)
                 continue;
-            const bool use_elig = !job.elig_only_if_band || (qflags & kFlagBandTouch);
-            bool ok = !(job.check_own_known || !use_elig) || (int)K[r] >= job.min_known;
+            bool ok = !(check_known || !use_elig) || (int)K[r] >= min_known;
             const unsigned long long key =
                 32268ull * K[r] + 499ull * (unsigned long long)S[r];
             bool broken = false;
-            for (int e = 0; e < job.n_elig && ok && use_elig; ++e) {
+            for (int e = 0; e < n_elig && ok && use_elig; ++e) {
                 const EligLevel& el = job.elig[e];
                 const size_t ni =
                     ((size_t)t * el.nxc + xi / el.div) * el.nyc + yi / el.div;
                 const uint32_t ck = el.k[ni];
-                ok = (int)ck >= job.min_known;
+                ok = (int)ck >= min_known;
                 /* the coarser node must bound this candidate; it can fail to
                  * only through the negative edge band */
                 const unsigned long long ckey =
@@ -613,20 +639,26 @@ __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S
             bound_broken |= broken;
             if (key == 0)
                 continue;
-            if (job.tie_list && key != *job.collect_key)
+            if (tie_list && key != collect_key)
                 continue;
-            const int L = job.rank_l;
-            const int nxc = job.nx / L, nyc = job.ny / L;
-            const unsigned long long rank =
-                ((((unsigned long long)t * nxc + xi / L) * nyc + yi / L) * L + xi % L) * L + yi % L;
-            if (job.tie_list) {
+            if (tie_list) {
+                const unsigned long long rank = (((rank_x + yq) * L + xm) * L) + ym;
                 const uint32_t pos = atomicAdd(job.tie_count, 1u);
                 if (pos < job.tie_cap)
-                    job.tie_list[pos] = rank;
+                    tie_list[pos] = rank;
                 continue;
             }
-            best_combine(bkey, brank, bcnt, key, rank, 1u);
+            if (key > bkey) {
+                bkey = key;
+                bcnt = 1;
+                best_yq = yq;
+                best_ym = ym;
+            } else if (key == bkey) {
+                ++bcnt;
+            }
         }
+        if (best_yq >= 0)
+            brank = (((rank_x + best_yq) * L + xm) * L) + best_ym;
     }
     if (!job.block_best)
         return;
