@@ -356,6 +356,7 @@ struct PassPlan {
     int cbx = 0, groups = 0, R = 0, ncbx = 0, ncby = 0, lstride = 0;
     bool weighted = true;     /* entries carry beam multiplicities */
     bool pairs = false;       /* pair-row fine kernel (k_score_pairs): lstride = slots per pair row */
+    int lists = 1;            /* entry lists in LDS: 2 = the batch kernel that takes two slices per workgroup */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -443,14 +444,20 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
  * block may be any width cbx <= LS - 65. */
 const int kPairLS[] = { 86, 98, 118, 130, 150, 162, 182 };
 
-size_t pair_lds_bytes(int ls, int cby)
+size_t pair_lds_bytes(int ls, int cby, int lists)
 {
     const size_t region = (size_t)((kTile + cby) / 2 + 1) * ls * 8;
-    return ((region + 1023) / 1024) * 1024 + (size_t)kPbMax * 4;
+    return ((region + 1023) / 1024) * 1024 + (size_t)lists * kPbMax * 4;
 }
 
-bool plan_pass_pairs(int nx, int ny, PassPlan* out)
+/* two_slices: plan for the batch kernel that takes two theta slices per workgroup
+ * (a second entry list in LDS) */
+bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
 {
+    const int lists = two_slices ? 2 : 1;
+    if (const char* e = getenv("CSM_PAIR_SLICES"))      /* tuning: 1 = one slice per workgroup everywhere */
+        if (atoi(e) == 1 && two_slices)
+            return plan_pass_pairs(nx, ny, out, false);
     if (const char* e = getenv("CSM_FINE_PAIRS"))       /* tuning / fallback knob */
         if (atoi(e) == 0)
             return false;
@@ -466,6 +473,7 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
         p.stride = 1;
         p.log2s = 0;
         p.pairs = true;
+        p.lists = lists;
         p.R = R;
         p.ncbx = ncbx;
         p.cbx = ceil_div(nx, ncbx);
@@ -479,9 +487,9 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out)
             continue;
         int g = std::min(std::min(kBlock / p.cbx, ceil_div(ny, R)), kPairMaxCby / R);
         /* two workgroups per CU: at most 80 KB of LDS each */
-        while (g > 1 && pair_lds_bytes(p.lstride, g * R) > 80 * 1024)
+        while (g > 1 && pair_lds_bytes(p.lstride, g * R, lists) > 80 * 1024)
             --g;
-        if (g < 1 || pair_lds_bytes(p.lstride, g * R) > 160 * 1024 - 256)
+        if (g < 1 || pair_lds_bytes(p.lstride, g * R, lists) > 160 * 1024 - 256)
             continue;
         p.ncby = ceil_div(ny, g * R);
         g = ceil_div(ceil_div(ny, p.ncby), R);          /* balance the row blocks */
@@ -528,7 +536,7 @@ int pick_buffers(size_t lds_one, long blocks)
 size_t pass_lds_bytes(const PassPlan& p)
 {
     if (p.pairs)
-        return pair_lds_bytes(p.lstride, p.groups * p.R);
+        return pair_lds_bytes(p.lstride, p.groups * p.R, p.lists);
     const int cby = p.groups * p.R;
     const int rows = p.stride > 1 ? ((kTile + p.stride - 1) / p.stride + cby - 1) * p.stride
                                   : kTile + cby - 1;
@@ -692,11 +700,20 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
 
 #define CALL_PAIRS_BATCH(LS, RR, WW)                                                   \
     do {                                                                               \
-        int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);                  \
-        if (rc_)                                                                       \
-            return rc_;                                                                \
-        hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
-                           ctx->stream, jobs_dev, pp.cbx, pp.groups);                  \
+        if (pp.lists == 2) {                                                           \
+            int rc_ = set_lds(ctx, k_score_pairs2_batch<LS, RR, WW>, lds);             \
+            if (rc_)                                                                   \
+                return rc_;                                                            \
+            hipLaunchKernelGGL((k_score_pairs2_batch<LS, RR, WW>),                     \
+                               dim3(grid.x, (grid.y + 1) / 2, grid.z), dim3(kBlock), lds, \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups);              \
+        } else {                                                                       \
+            int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);              \
+            if (rc_)                                                                   \
+                return rc_;                                                            \
+            hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups);              \
+        }                                                                              \
     } while (0)
 
 int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta, int n_slices)
@@ -2249,7 +2266,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     /* ---- launch geometry shared by the group ---- */
     std::vector<PassPlan> lp(H + 1);
     for (int h = 0; h <= H; ++h) {
-        if (h == 0 && plan_pass_pairs(nx, ny, &lp[0]))
+        if (h == 0 && plan_pass_pairs(nx, ny, &lp[0], true))
             continue;
         if (!plan_pass(nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
             return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,

@@ -28,8 +28,10 @@ struct TileRec {
     uint32_t start;      /* first beam in the slice's sorted list */
     uint32_t count;
     int32_t  h, w;       /* bounding box extent, cells (<= kTile) */
-    int32_t  pad[2];     /* entries of class "both rows" / "even row only" in this record
-                            (the rest: "odd row only"); single mode: 0, count */
+    int32_t  pad[2];     /* [0]: entries of class "both rows" | "even row only" << 16 in this
+                            record (the rest: "odd row only"); single mode: 0 | count << 16.
+                            [1]: tile number << 4 | chunk of the tile (records of one slice
+                            ascend in it: slices are merged tile by tile on it) */
 };
 
 static_assert(sizeof(TileRec) == 32, "copied into LDS as two uint4");

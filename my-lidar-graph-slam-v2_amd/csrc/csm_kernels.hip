@@ -108,7 +108,8 @@ constexpr int kBinDebugRows = 65536;
  * reads both rows with one ds_read_b64, so a vertical run of hit cells costs
  * about half the LDS reads. Entries of a tile are sorted by class (both rows
  * hit / even row only / odd row only) so that the gather loops have no
- * per-entry branch; TileRec.pad[0..1] hold the first two class counts.
+ * per-entry branch; TileRec.pad[0] holds the first two class counts (16 bits
+ * each), pad[1] the tile's number and the record's chunk number within it.
  *
  * Entry words:
  *   sorted_pb, single mode: mult << 16 | (row * lstride + col)
@@ -425,8 +426,9 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
                 /* class counts of this chunk: entries [done, done + count) of the tile's
                  * list [both | even only | odd only] */
                 const uint32_t end = done + rec.count;
-                rec.pad[0] = (int)(min(end, nb) - min(done, nb));
-                rec.pad[1] = (int)(min(end, nb + nev) - min(max(done, nb), nb + nev));
+                rec.pad[0] = (int)((min(end, nb) - min(done, nb)) |
+                                   ((min(end, nb + nev) - min(max(done, nb), nb + nev)) << 16));
+                rec.pad[1] = (int)(((uint32_t)i << 4) | (done / kPbMax));   /* tile, chunk of the tile */
                 recs[slot_rec++] = rec;
             }
             cnt64[i] = (unsigned long long)off | ((unsigned long long)(off + nb) << 21) |
@@ -1160,8 +1162,9 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         const int cnt = __builtin_amdgcn_readfirstlane((int)rec.count);
         const int start = __builtin_amdgcn_readfirstlane((int)rec.start);
         const int nprows = (__builtin_amdgcn_readfirstlane(rec.h) + cby) >> 1;
-        const int end_both = __builtin_amdgcn_readfirstlane(rec.pad[0]);
-        const int end_even = end_both + __builtin_amdgcn_readfirstlane(rec.pad[1]);
+        const int classes = __builtin_amdgcn_readfirstlane(rec.pad[0]);
+        const int end_both = classes & 0xffff;
+        const int end_even = end_both + (classes >> 16);
         const int npieces = (nprows * kRowBytes + 1023) >> 10;
         const char* src = xg + ((size_t)((gr0 + pad) >> 1) * xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
         if (ti + n_slices < ntiles)
@@ -1293,6 +1296,270 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags);
 }
 
+/* ---- two theta slices per workgroup ---------------------------------------
+ * Neighbouring slices (0.25 - 0.5 degrees apart) put their beams on the same
+ * endpoint tiles, one or two cells apart. A workgroup of the batch kernel takes
+ * slices 2k and 2k + 1, walks the two record lists together (records ascend in
+ * TileRec.pad[1] = tile, chunk), stages ONE window per tile -- the union of the
+ * two bounding boxes -- and gathers the entries of both slices from it into two
+ * sets of accumulators: the barriers, the DMA wait and the window copy of a tile
+ * are paid once per two slices (they were 29 % + 6 % of the single-slice kernel). */
+
+/* The entries of one slice's record from the staged window: exactly the gather of
+ * score_body_pairs (see there for the rules of the hand-issued reads). */
+template <int LS, int R, bool WEIGHTED>
+__device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t* lpb, int lane, int cnt,
+                                             int end_both, int end_even, uint32_t (&acc)[R],
+                                             uint32_t (&S)[R], uint32_t (&K)[R], int& pending)
+{
+    constexpr int kRowBytes = LS * 8;
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S[r] += acc[r] & 0x7fffffu;
+            K[r] += acc[r] >> 23;
+            acc[r] = 0;
+        }
+        pending = 0;
+    };
+    auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
+        constexpr int CLS = decltype(cls)::value;
+        const uint32_t addr = lane_addr + (pbv & 0x7ffffu);
+        lds_read_b64<0 * kRowBytes>(addr, q[0]);
+        lds_read_b64<1 * kRowBytes>(addr, q[1]);
+        if (R >= 6)
+            lds_read_b64<2 * kRowBytes>(addr, q[2]);
+        if (R >= 8)
+            lds_read_b64<3 * kRowBytes>(addr, q[3]);
+        if (CLS != 1)
+            lds_read_b64<(R / 2) * kRowBytes>(addr, q[R / 2]);
+    };
+    auto mads = [&](uint32_t pbv, auto cls, const unsigned long long (&q)[R / 2 + 1]) {
+        constexpr int CLS = decltype(cls)::value;
+        uint32_t v[R + 2];
+#pragma unroll
+        for (int i = 0; i < R / 2 + 1; ++i) {
+            v[2 * i] = (uint32_t)q[i];
+            v[2 * i + 1] = (uint32_t)(q[i] >> 32);
+        }
+        const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
+        if (WEIGHTED) {
+            if (CLS != 2) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r] = mad_u24(v[r], me, acc[r]);
+            }
+            if (CLS != 1) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r] = mad_u24(v[r + 1], mo, acc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (CLS == 0)
+                    acc[r] += v[r] + v[r + 1];
+                else
+                    acc[r] += v[CLS == 1 ? r : r + 1];
+            }
+        }
+    };
+    auto beams_of = [&](uint32_t pbv) { return (int)((pbv >> 19) & 31u); };
+    int j = 0;
+    uint32_t pb_cur = lpb[lane];
+    auto run = [&](int end, auto cls) {
+        constexpr int CLS = decltype(cls)::value;
+        constexpr int NP = CLS == 1 ? R / 2 : R / 2 + 1;
+        constexpr int NQ = R / 2 + 1;
+        while (j < end) {
+            const int stop = min(end, (j | 63) + 1);
+            for (; j + 4 <= stop; j += 4) {
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
+                const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
+                const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
+                const int mm = beams_of(o0) + beams_of(o1) + beams_of(o2) + beams_of(o3);
+                if (pending + mm > 128)
+                    flush();
+                pending += mm;
+                unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ];
+                issue(o0, cls, qa);
+                issue(o1, cls, qb);
+                lds_wait<NP, NQ>(qa);
+                mads(o0, cls, qa);
+                issue(o2, cls, qc);
+                lds_wait<NP, NQ>(qb);
+                mads(o1, cls, qb);
+                issue(o3, cls, qd);
+                lds_wait<NP, NQ>(qc);
+                mads(o2, cls, qc);
+                lds_wait<0, NQ>(qd);
+                mads(o3, cls, qd);
+            }
+            for (; j < stop; ++j) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+                const int mm = beams_of(o);
+                if (pending + mm > 128)
+                    flush();
+                pending += mm;
+                unsigned long long qa[NQ];
+                issue(o, cls, qa);
+                lds_wait<0, NQ>(qa);
+                mads(o, cls, qa);
+            }
+            if ((j & 63) == 0 && j < cnt)
+                pb_cur = lpb[j + lane];
+        }
+    };
+    run(end_both, std::integral_constant<int, 0>());
+    run(end_even, std::integral_constant<int, 1>());
+    run(cnt, std::integral_constant<int, 2>());
+}
+
+template <int LS, int R, bool WEIGHTED>
+__device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups)
+{
+    static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
+    const int t0 = 2 * (int)blockIdx.y, t1 = t0 + 1;
+    /* values loaded from the job are uniform, but only readfirstlane tells the compiler:
+     * everything derived from them then stays in scalar registers and scalar branches */
+    const int n_theta = __builtin_amdgcn_readfirstlane(job.n_theta);
+    if (t0 >= n_theta)
+        return;
+    const bool two = t1 < n_theta;
+    const int tid = threadIdx.x;
+    const int ncbx = (job.nx + cbx - 1) / cbx;
+    const int bx = blockIdx.x % ncbx, by = blockIdx.x / ncbx;
+    const int cby = groups * R;
+    if (by * cby >= job.ny)
+        return;
+    const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
+
+    const int dxi = tid % cbx, g = tid / cbx;
+    const bool lane_on = g < groups;
+    const int x0 = job.x_lo + bx * cbx;
+    const int y0 = job.y_lo + by * cby;
+    constexpr int kRowBytes = LS * 8;
+    const int prows_full = (kTile + cby) / 2 + 1;
+    const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
+    uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
+    uint32_t* lpb0 = sm_cells + max_pieces * 256;
+    uint32_t* lpb1 = lpb0 + kPbMax;
+    const int tb = lane_on ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    uint32_t S0[R], K0[R], acc0[R], S1[R], K1[R], acc1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        S0[r] = K0[r] = acc0[r] = S1[r] = K1[r] = acc1[r] = 0;
+    int pending0 = 0, pending1 = 0;
+
+    const bool gather = !job.in_s;
+    const int n0 = __builtin_amdgcn_readfirstlane(gather ? job.n_tiles[t0] : 0);
+    const int n1 = __builtin_amdgcn_readfirstlane(gather && two ? job.n_tiles[t1] : 0);
+    const TileRec* recs0 = job.tiles + (size_t)t0 * job.max_tiles;
+    const TileRec* recs1 = job.tiles + (size_t)t1 * job.max_tiles;
+    const uint32_t* __restrict__ pbs0 = job.sorted_pb + (size_t)t0 * job.n_points;
+    const uint32_t* __restrict__ pbs1 = job.sorted_pb + (size_t)t1 * job.n_points;
+    const size_t xg_pitch = (size_t)job.xg_pitch;
+    const size_t xg_row_bytes = xg_pitch * 8;
+    const char* xg = reinterpret_cast<const char*>(job.xg);
+    const int pad = job.xg_pad;
+
+    constexpr int kMaxP = ((((kTile + kPairMaxCby) / 2 + 1) * kRowBytes + 1023) / 1024 + 7) / 8;
+    uint32_t goff[kMaxP];
+#pragma unroll
+    for (int k = 0; k < kMaxP; ++k) {
+        const uint32_t ob = (uint32_t)(wave + 8 * k) * 1024u + (uint32_t)lane * 16u;
+        const uint32_t prow = ob / (uint32_t)kRowBytes, cb = ob - prow * (uint32_t)kRowBytes;
+        goff[k] = prow * (uint32_t)xg_row_bytes + cb;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    TileRec ra, rb;
+    int i0 = 0, i1 = 0;
+    if (n0 > 0)
+        ra = recs0[0];
+    if (n1 > 0)
+        rb = recs1[0];
+    const int kNone = 0x7fffffff;
+    while (i0 < n0 || i1 < n1) {
+        /* wave-uniform values of the records at the two cursors */
+        const int key0 = i0 < n0 ? __builtin_amdgcn_readfirstlane(ra.pad[1]) : kNone;
+        const int key1 = i1 < n1 ? __builtin_amdgcn_readfirstlane(rb.pad[1]) : kNone;
+        const int key = min(key0, key1);
+        const bool use0 = key0 == key, use1 = key1 == key;
+        const int r00 = __builtin_amdgcn_readfirstlane(ra.r0), c00_ = __builtin_amdgcn_readfirstlane(ra.c0);
+        const int h0 = __builtin_amdgcn_readfirstlane(ra.h);
+        const int r01 = __builtin_amdgcn_readfirstlane(rb.r0), c01_ = __builtin_amdgcn_readfirstlane(rb.c0);
+        const int h1 = __builtin_amdgcn_readfirstlane(rb.h);
+        const int cnt0 = use0 ? __builtin_amdgcn_readfirstlane((int)ra.count) : 0;
+        const int cnt1 = use1 ? __builtin_amdgcn_readfirstlane((int)rb.count) : 0;
+        const int start0 = __builtin_amdgcn_readfirstlane((int)ra.start);
+        const int start1 = __builtin_amdgcn_readfirstlane((int)rb.start);
+        const int cls0 = __builtin_amdgcn_readfirstlane(ra.pad[0]);
+        const int cls1 = __builtin_amdgcn_readfirstlane(rb.pad[0]);
+        /* the union of the bounding boxes (r0 even in both) */
+        const int ru = use0 && use1 ? min(r00, r01) : use0 ? r00 : r01;
+        const int cu = use0 && use1 ? min(c00_, c01_) : use0 ? c00_ : c01_;
+        const int re = use0 && use1 ? max(r00 + h0, r01 + h1) : use0 ? r00 + h0 : r01 + h1;
+        const int c00 = cu + x0;
+        const int gr0 = ru + y0;
+        const int a = c00 & 1;
+        const int nprows = (re - ru + cby) >> 1;
+        const int npieces = (nprows * kRowBytes + 1023) >> 10;
+        /* where each slice's box starts inside the staged window, bytes */
+        const int shift0 = ((r00 - ru) >> 1) * kRowBytes + (c00_ - cu) * 8;
+        const int shift1 = ((r01 - ru) >> 1) * kRowBytes + (c01_ - cu) * 8;
+        const char* src = xg + ((size_t)((gr0 + pad) >> 1) * xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
+        if (use0 && ++i0 < n0)
+            ra = recs0[i0];
+        if (use1 && ++i1 < n1)
+            rb = recs1[i1];
+        __syncthreads();                                 /* previous tile consumed */
+#pragma unroll
+        for (int k = 0; k < kMaxP; ++k) {
+            const int pc = wave + 8 * k;
+            if (pc < npieces)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(src + goff[k]), (lds_ptr)(sm_cells + pc * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < kPbMax / 64 / 8; ++e) {
+            const int pe = wave + 8 * e;
+            if (pe * 64 < cnt0)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(pbs0 + start0 + pe * 64 + lane),
+                                                 (lds_ptr)(lpb0 + pe * 64), 4, 0, 0);
+            if (pe * 64 < cnt1)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(pbs1 + start1 + pe * 64 + lane),
+                                                 (lds_ptr)(lpb1 + pe * 64), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
+        if (cnt0 > 0)
+            pairs_gather<LS, R, WEIGHTED>(lane_addr + (uint32_t)shift0, lpb0, lane, cnt0, cls0 & 0xffff,
+                                          (cls0 & 0xffff) + (cls0 >> 16), acc0, S0, K0, pending0);
+        if (cnt1 > 0)
+            pairs_gather<LS, R, WEIGHTED>(lane_addr + (uint32_t)shift1, lpb1, lane, cnt1, cls1 & 0xffff,
+                                          (cls1 & 0xffff) + (cls1 >> 16), acc1, S1, K1, pending1);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        S0[r] += acc0[r] & 0x7fffffu;
+        K0[r] += acc0[r] >> 23;
+        S1[r] += acc1[r] & 0x7fffffu;
+        K1[r] += acc1[r] >> 23;
+    }
+    score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+    if (two) {
+        __syncthreads();                                 /* the epilogue's reduction arrays */
+        score_epilogue<R>(job, S1, K1, t1, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+    }
+}
+
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups)
 {
@@ -1304,6 +1571,13 @@ template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups)
 {
     score_body_pairs<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, 0, 1);
+}
+
+/* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
+template <int LS, int R, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs2_batch(const ScoreJob* jobs, int cbx, int groups)
+{
+    score_body_pairs2<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups);
 }
 
 /* ------------------------------------------------------------------ K2 */
