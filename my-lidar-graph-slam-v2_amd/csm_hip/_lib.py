@@ -6,7 +6,9 @@ the import fails, and without a GPU every compute entry point returns
 CSM_ENODEV.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSM_HIP_LIB: a tuning build of the same library (tools/build_variant.sh), for A/B runs on one box
@@ -217,6 +219,13 @@ def load():
         raise ImportError(
             "libcsm_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(expected at %s)" % LIB_PATH)
+    # A process that also uses PyTorch must end up with ONE HIP runtime: torch ships its
+    # own libamdhip64, and whichever of the two runtimes initialises second finds no GPU.
+    # Importing torch first makes libcsm_hip.so bind to the copy torch has already loaded
+    # (the configuration every GPU test and bench.py run in). Without torch installed the
+    # library uses /opt/rocm's runtime, as a C++ caller does.
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

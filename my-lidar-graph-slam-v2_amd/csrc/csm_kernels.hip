@@ -2105,32 +2105,47 @@ __device__ __forceinline__ void proj_body(const ProjJob& job)
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= job.n_points)
         return;
+    /* every job field the slice loop needs, read once (the stores below may alias the
+     * job as far as the compiler knows); 1 / res replaces the divisions: f64 division
+     * was most of this kernel, and the quotient only has to be good to the bound */
     const double a = job.angles[i];
     const double r = job.ranges[i];
-    const double bb = job.sensor_theta + a;
+    const double sensor_x = job.sensor_x, sensor_y = job.sensor_y, sensor_theta = job.sensor_theta;
+    const double off_x = job.off_x, off_y = job.off_y, res = job.res, inv_res = 1.0 / job.res;
+    const double step_theta = job.step_theta, step_x = job.step_x, step_y = job.step_y;
+    const int n_points = job.n_points, win_theta = job.win_theta;
+    const int x_lo = job.x_lo, y_lo = job.y_lo, nx = job.nx, ny = job.ny;
+    const bool check_nodes = job.check_nodes != 0, flag_uncertain = job.flag_uncertain != 0;
+    int32_t* const hit_col = job.hit_col;
+    int32_t* const hit_row = job.hit_row;
+    const double bb = sensor_theta + a;
     const double cb = cos(bb), sb = sin(bb);
-    const double ang = fabs(job.sensor_theta) + fabs(a);
+    const double ang = fabs(sensor_theta) + fabs(a);
     /* branch and bound: the widest node offsets, once per beam */
-    const double xr = fmax(fabs((double)job.x_lo), fabs((double)(job.x_lo + job.nx - 1))) * job.step_x;
-    const double yr = fmax(fabs((double)job.y_lo), fabs((double)(job.y_lo + job.ny - 1))) * job.step_y;
-    const bool unit_step = job.step_x == job.res && job.step_y == job.res;
+    const double xr = fmax(fabs((double)x_lo), fabs((double)(x_lo + nx - 1))) * step_x;
+    const double yr = fmax(fabs((double)y_lo), fabs((double)(y_lo + ny - 1))) * step_y;
+    const bool unit_step = step_x == res && step_y == res;
+    /* a quotient formed as (h - off) * (1 / res): two roundings more than a division */
+    auto err_bound = [&](double hit, double off, double q, double trig_err) {
+        return (fabs(r) * trig_err + (fabs(hit) + fabs(off)) * 4e-16) * inv_res + fabs(q) * 8e-16;
+    };
     for (int k = 0; k < n_local; ++k) {
         const int t = (int)blockIdx.y + k * (int)gridDim.y;
         const double cd = tab_c[k], sd = tab_s[k];
-        const double trig_err = 2.4e-15 + 4e-16 * (ang + fabs(job.step_theta * (t - job.win_theta)));
+        const double trig_err = 2.4e-15 + 4e-16 * (ang + fabs(step_theta * (t - win_theta)));
         const double rc = r * (cb * cd - sb * sd);
         const double rs = r * (sb * cd + cb * sd);
-        const double hx = job.sensor_x + rc, hy = job.sensor_y + rs;
-        const double qx = (hx - job.off_x) / job.res, qy = (hy - job.off_y) / job.res;
+        const double hx = sensor_x + rc, hy = sensor_y + rs;
+        const double qx = (hx - off_x) * inv_res, qy = (hy - off_y) * inv_res;
         const double fx = floor(qx), fy = floor(qy);
-        const double mx = 64.0 * proj_err_bound(r, hx, job.off_x, job.res, qx, trig_err);
-        const double my = 64.0 * proj_err_bound(r, hy, job.off_y, job.res, qy, trig_err);
-        const size_t idx = (size_t)t * job.n_points + i;
+        const double mx = 64.0 * err_bound(hx, off_x, qx, trig_err);
+        const double my = 64.0 * err_bound(hy, off_y, qy, trig_err);
+        const size_t idx = (size_t)t * n_points + i;
         const int col = (int)fx, row = (int)fy;
-        job.hit_col[idx] = col;
-        job.hit_row[idx] = row;
+        hit_col[idx] = col;
+        hit_row[idx] = row;
         bool uncertain = !(qx - fx > mx && qx - fx < 1.0 - mx && qy - fy > my && qy - fy < 1.0 - my);
-        if (job.check_nodes && !uncertain) {
+        if (check_nodes && !uncertain) {
             /* appendNode's pose (scan_matcher_branch_bound.cpp:156-176):
              * floor(((sensor + x*step) + r*trig - off) / res) must equal base + x for
              * every node offset x. The search step IS the resolution
@@ -2138,31 +2153,31 @@ __device__ __forceinline__ void proj_body(const ProjJob& job)
              * node coordinate is q + x; every rounding on the way is bounded, hence
              * one test per beam and axis certifies all offsets at once. Only beams
              * within that (slightly wider) margin of a cell edge walk the offsets. */
-            const double wx = 64.0 * ((fabs(r) * trig_err + (fabs(hx) + xr + fabs(job.off_x)) * 8e-16) / job.res +
-                                      (fabs(qx) + xr / job.res) * 8e-16);
-            const double wy = 64.0 * ((fabs(r) * trig_err + (fabs(hy) + yr + fabs(job.off_y)) * 8e-16) / job.res +
-                                      (fabs(qy) + yr / job.res) * 8e-16);
+            const double wx = 64.0 * ((fabs(r) * trig_err + (fabs(hx) + xr + fabs(off_x)) * 8e-16) * inv_res +
+                                      (fabs(qx) + xr * inv_res) * 1.2e-15);
+            const double wy = 64.0 * ((fabs(r) * trig_err + (fabs(hy) + yr + fabs(off_y)) * 8e-16) * inv_res +
+                                      (fabs(qy) + yr * inv_res) * 1.2e-15);
             const bool sure_x = unit_step && qx - fx > wx && qx - fx < 1.0 - wx;
             const bool sure_y = unit_step && qy - fy > wy && qy - fy < 1.0 - wy;
-            for (int xi = 0; xi < job.nx && !sure_x && !uncertain; ++xi) {
-                const int x = job.x_lo + xi;
-                const double h = (job.sensor_x + x * job.step_x) + rc;
-                const double q = (h - job.off_x) / job.res;
+            for (int xi = 0; xi < nx && !sure_x && !uncertain; ++xi) {
+                const int x = x_lo + xi;
+                const double h = (sensor_x + x * step_x) + rc;
+                const double q = (h - off_x) * inv_res;
                 const double f = floor(q);
-                const double m = 64.0 * proj_err_bound(r, h, job.off_x, job.res, q, trig_err);
+                const double m = 64.0 * err_bound(h, off_x, q, trig_err);
                 uncertain = !((int)f == col + x && q - f > m && q - f < 1.0 - m);
             }
-            for (int yi = 0; yi < job.ny && !sure_y && !uncertain; ++yi) {
-                const int y = job.y_lo + yi;
-                const double h = (job.sensor_y + y * job.step_y) + rs;
-                const double q = (h - job.off_y) / job.res;
+            for (int yi = 0; yi < ny && !sure_y && !uncertain; ++yi) {
+                const int y = y_lo + yi;
+                const double h = (sensor_y + y * step_y) + rs;
+                const double q = (h - off_y) * inv_res;
                 const double f = floor(q);
-                const double m = 64.0 * proj_err_bound(r, h, job.off_y, job.res, q, trig_err);
+                const double m = 64.0 * err_bound(h, off_y, q, trig_err);
                 uncertain = !((int)f == row + y && q - f > m && q - f < 1.0 - m);
             }
         }
         if (uncertain) {
-            if (job.check_nodes || job.flag_uncertain) {
+            if (check_nodes || flag_uncertain) {
                 atomicOr(job.flags, CSM_FLAG_PROJ_DELTA);
             } else {
                 const uint32_t pos = atomicAdd(job.unc_count, 1u);

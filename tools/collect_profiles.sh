@@ -51,9 +51,9 @@ def counters(name):
                 d = acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], [0.0, 0])
                 d[0] += float(row["Counter_Value"]); d[1] += 1
     return {k: {c: {"mean_KB": s / n, "dispatches": n} for c, (s, n) in v.items()} for k, v in acc.items()}
-for name, pick, wpl in (("csm", "k_score_pairs_batch", 64), ("cfg5", "k_score_pairs<", 1)):
+for name, pick, wpl in (("csm", "_batch<", 64), ("cfg5", "k_score_pairs<", 1)):
     per = counters(name)
-    dom = [k for k in per if pick in k]
+    dom = [k for k in per if pick in k and "k_score_pairs" in k]
     if name == "cfg5":      # the 2000x2000 query's kernel: the single-window pair kernel with the widest rows
         dom = [k for k in dom if "182" in k] or dom
     doc = {"library_version": version, "windows_per_launch": wpl, "per_kernel": per,
