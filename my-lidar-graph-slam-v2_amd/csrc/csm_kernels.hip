@@ -136,7 +136,14 @@ constexpr int kBinDebugRows = 65536;
 __device__ __forceinline__ void k_bin_body(const BinJob& job)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm_bin[];
-    const int ntile = job.tiles_x * job.tiles_y;
+    /* the job's fields are the same for every lane, but loaded through a reference the
+     * compiler treats them as per-lane values: readfirstlane keeps the loop bounds, the
+     * table sizes and everything derived from them in scalar registers and branches */
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int tiles_x = uni(job.tiles_x);
+    const int ntile = tiles_x * uni(job.tiles_y);
+    const int hash_size = uni(job.hash_size);
+    const int n_theta_job = uni(job.n_theta);
     /* per tile: entry counts (later the cursors) of the three classes, 21 bits each,
      * in one 64-bit word -- total | both << 21 | even-only << 42 -- and the hit rows /
      * columns of the tile as bit masks (bounding box = lowest / highest set bit): three
@@ -146,20 +153,20 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     unsigned long long* rowmask = cnt64 + ntp;                                    /* [ntp] */
     unsigned long long* colmask = rowmask + ntp;                                  /* [ntp] */
     uint32_t* hkey = reinterpret_cast<uint32_t*>(colmask + ntp);   /* [hash_size] (tile, cell) + 1, 0 = empty */
-    uint32_t* hval = hkey + job.hash_size;   /* [hash_size] beams on that cell: even row | odd row << 16 */
+    uint32_t* hval = hkey + hash_size;   /* [hash_size] beams on that cell: even row | odd row << 16 */
     /* occupied slots (< 32768), [n_points]: a segment per wave */
-    uint16_t* list = reinterpret_cast<uint16_t*>(hval + job.hash_size);
+    uint16_t* list = reinterpret_cast<uint16_t*>(hval + hash_size);
     __shared__ uint32_t seg_n[kBinBlock / 64];   /* cells claimed by each wave */
     const int t = blockIdx.x;
-    if (t >= job.n_theta)
+    if (t >= n_theta_job)
         return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int n = job.n_points;
+    const int n = uni(job.n_points);
     const int32_t* col = job.hit_col + (size_t)t * n;
     const int32_t* row = job.hit_row + (size_t)t * n;
-    const uint32_t hmask = (uint32_t)job.hash_size - 1u;
-    const bool pairs = job.pair_mode != 0;
+    const uint32_t hmask = (uint32_t)hash_size - 1u;
+    const bool pairs = uni(job.pair_mode) != 0;
 #ifdef CSM_BIN_TIMING
     unsigned long long tick_ = __builtin_readcyclecounter();
     const size_t dbg_row_ = min((size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)kBinDebugRows - 1);
@@ -187,7 +194,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         cnt64[i] = 0ull;
     {
         uint4* h4 = reinterpret_cast<uint4*>(hkey);      /* hkey and hval are contiguous */
-        for (int i = tid; i < job.hash_size / 2; i += kBinBlock)
+        for (int i = tid; i < hash_size / 2; i += kBinBlock)
             h4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
@@ -199,13 +206,12 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
      * with the run's beam counts (same-address LDS atomics of a wave serialise). The
      * lane that claims an empty slot appends it to `list`: passes B and C walk the
      * distinct cells, not the table. */
-    const int r_max = job.rows - 1 - job.y_lo;
-    const int c_max = job.cols - 1 - job.x_lo;
+    const int r_max = uni(job.rows) - 1 - uni(job.y_lo);
+    const int c_max = uni(job.cols) - 1 - uni(job.x_lo);
     bool band = false;
-    const int fs = job.frame_shift;          /* 0 / 1: see BinJob */
-    const int x_hi = job.x_hi, y_hi = job.y_hi, x_lo = job.x_lo, y_lo = job.y_lo;
-    const int tiles_x = job.tiles_x;
-    const int n_band = job.n_band;
+    const int fs = uni(job.frame_shift);     /* 0 / 1: see BinJob */
+    const int x_hi = uni(job.x_hi), y_hi = uni(job.y_hi), x_lo = uni(job.x_lo), y_lo = uni(job.y_lo);
+    const int n_band = uni(job.n_band);
     const int n_iter = (n + kBinBlock - 1) / kBinBlock;
 #ifdef CSM_BIN_TIMING
     unsigned long long sub_[4] = { 0, 0, 0, 0 }, subt_ = 0;
@@ -218,7 +224,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
         const int m = (-u) % w;              /* v = -m */
         return m != 0 && w - 1 - m >= known_lo;
     };
-    const int known_r0 = job.known_r0, known_c0 = job.known_c0;
+    const int known_r0 = uni(job.known_r0), known_c0 = uni(job.known_c0);
     const int wave = tid >> 6;
     /* a wave can claim one slot per beam it handles (i = it * kBinBlock + wave * 64 + lane):
      * its segment of the list starts after the beams of the waves before it */
@@ -333,11 +339,12 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     BIN_TICK(1);
 
     /* the host decides per query whether merging pays (job.max_mult 1 = off) */
-    const uint32_t max_mult = (uint32_t)job.max_mult;
+    const uint32_t max_mult = (uint32_t)uni(job.max_mult);
     auto chunks = [&](uint32_t beams) { return (beams + max_mult - 1u) / max_mult; };
     static_assert(kBinBlock == 256, "four list segments");
-    const uint32_t seg1 = seg_n[0], seg2 = seg1 + seg_n[1], seg3 = seg2 + seg_n[2];
-    const int n_cells = (int)(seg3 + seg_n[3]);
+    const uint32_t seg1 = (uint32_t)uni((int)seg_n[0]), seg2 = seg1 + (uint32_t)uni((int)seg_n[1]),
+                   seg3 = seg2 + (uint32_t)uni((int)seg_n[2]);
+    const int n_cells = uni((int)(seg3 + seg_n[3]));
     auto cell_slot = [&](int e) {
         const uint32_t ue = (uint32_t)e;
         const uint32_t sg = (ue >= seg1) + (ue >= seg2) + (ue >= seg3);
@@ -442,7 +449,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
     /* Pass C: the entries */
     uint32_t* out = job.sorted_pb + (size_t)t * n;
     uint32_t* out_rc = job.sorted_rc ? job.sorted_rc + (size_t)t * n : nullptr;
-    const uint32_t lstride = (uint32_t)job.lstride;
+    const uint32_t lstride = (uint32_t)uni(job.lstride);
     for (int e = tid; e < n_cells; e += kBinBlock) {
         const uint32_t sl = cell_slot(e);
         const uint32_t k1 = hkey[sl] - 1u, hv = hval[sl];
