@@ -320,6 +320,9 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
                                    "memory, query array marshalled once, maps and pyramids resident)"
                                    % (3 if strong else 2, n_total),
                        "queries_total": n_total, "queries_per_rank": hi - lo,
+                       "single_gpu_base": "configs.config4_one_gpu of the N = 1 line is this workload on one "
+                                          "GPU (the N = 1 headline itself is configs[1], another workload)"
+                       if strong else None,
                        "leaves_per_step": leaves, "found": found,
                        "parallelism": "contiguous query blocks per GPU, one all-gather of 48-B records "
                                       "per step (%s)" % ("gloo rehearsal" if rehearse else "RCCL")
