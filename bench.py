@@ -4,7 +4,7 @@
 N = 1 (default): BASELINE.json configs[1] -- frontend CSM, 1080-beam scan over
 270 deg, 400x400 grid @ 5 cm, +-2 m / +-30 deg window at 5 cm / 0.5 deg, L = 4
 (123 x 84 x 84 = 867,888 candidate poses per scan, 2160 algorithmic bytes
-each). One step = SCANS_PER_STEP (2560) scans, hit indices and grid already
+each). One step = SCANS_PER_STEP (3072) scans, hit indices and grid already
 resident in HBM, scored 64 windows per batched launch chain
 (csm_score_windows_dev), so that the K timed steps last seconds, not
 milliseconds. The same line carries, under "configs", short driver-timed runs
@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "my-lidar-graph-slam-v2_amd"))
 
 WINDOWS_PER_LAUNCH = 64
-SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "2560"))     # scans per step
+SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "3072"))     # scans per step
 DISTINCT_SCANS = int(os.environ.get("CSM_BENCH_DISTINCT", "256"))    # different scans generated
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # MI355X_MICROARCH.md, LDS: 64 banks x 4 B per clock per CU (ds_read_b64 / b128

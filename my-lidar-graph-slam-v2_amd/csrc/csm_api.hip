@@ -134,6 +134,9 @@ struct csm_ctx {
     int timing = 0;               /* 0 off, 1 every kernel, 2 the fine scoring kernel only */
     std::map<std::string, KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
+    /* pinned staging blocks of the batch entries' job tables, reused once the copy
+     * that reads them has run */
+    std::vector<std::pair<void*, size_t>> pin_free;
 };
 
 namespace {
@@ -1434,6 +1437,9 @@ int csm_destroy(csm_ctx* ctx)
         }
     for (auto& h : ctx->resident_hold)
         (void)hipEventDestroy(h.first);
+    ctx->resident_hold.clear();           /* returns the blocks they hold to pin_free */
+    for (auto& b : ctx->pin_free)
+        (void)hipHostFree(b.first);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->m_ev)
@@ -2496,16 +2502,42 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         Z.flags_in = d_flags + k;
         Z.out = resident ? resident->out_dev + idx[k] : d_out + k;
     }
-    /* upload the job tables (one buffer, 16-byte aligned sections) */
-    char* jb = reinterpret_cast<char*>(ctx->b_jobs.p);
+    /* upload the job tables: one device buffer with 256-byte aligned sections, filled
+     * from one pinned block by ONE copy (five copies from pageable vectors cost 18 us per
+     * 64-window chain and a staging pass each) */
+    const size_t tables_cap = jobs_bytes + (size_t)nq * 4 + 256 * (size_t)(H + 10);
+    if ((rc = ensure(ctx, ctx->b_jobs, tables_cap))) return rc;
+    std::shared_ptr<std::pair<void*, size_t>> pin_block;
+    {
+        std::pair<void*, size_t> blk(nullptr, 0);
+        for (size_t b = 0; b < ctx->pin_free.size(); ++b)
+            if (ctx->pin_free[b].second >= tables_cap) {
+                blk = ctx->pin_free[b];
+                ctx->pin_free.erase(ctx->pin_free.begin() + b);
+                break;
+            }
+        if (!blk.first) {
+            const size_t cap = tables_cap + tables_cap / 4 + 4096;
+            if (hipHostMalloc(&blk.first, cap, hipHostMallocDefault) != hipSuccess)
+                return fail(ctx, CSM_ENOMEM, "hipHostMalloc(%zu) failed", cap);
+            blk.second = cap;
+        }
+        csm_ctx* owner = ctx;
+        pin_block = std::shared_ptr<std::pair<void*, size_t>>(
+            new std::pair<void*, size_t>(blk), [owner](std::pair<void*, size_t>* b) {
+                owner->pin_free.push_back(*b);
+                delete b;
+            });
+    }
+    char* const jb0 = reinterpret_cast<char*>(ctx->b_jobs.p);
+    char* const hb0 = reinterpret_cast<char*>(pin_block->first);
+    size_t tables_off = 0;
     auto put = [&](const void* src, size_t bytes, char** dev) -> hipError_t {
-        *dev = jb;
-        jb += (bytes + 255) & ~(size_t)255;
-        return hipMemcpyAsync(*dev, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        *dev = jb0 + tables_off;
+        std::memcpy(hb0 + tables_off, src, bytes);
+        tables_off += (bytes + 255) & ~(size_t)255;
+        return tables_off <= tables_cap ? hipSuccess : hipErrorInvalidValue;
     };
-    /* sections were sized without the 256-byte rounding: grow if needed */
-    if ((rc = ensure(ctx, ctx->b_jobs, jobs_bytes + (size_t)nq * 4 + 256 * (size_t)(H + 10)))) return rc;
-    jb = reinterpret_cast<char*>(ctx->b_jobs.p);
     char *d_ij, *d_bj, *d_fj, *d_idx = nullptr, *d_zj = nullptr;
     if (H > 0)
         HIP_TRY(ctx, put(zj.data(), zj.size() * sizeof(ZeroJob), &d_zj));
@@ -2517,6 +2549,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     HIP_TRY(ctx, put(fj.data(), nq * sizeof(FinalJob), &d_fj));
     for (int h = 0; h <= H; ++h)
         HIP_TRY(ctx, put(sj[h].data(), nq * sizeof(ScoreJob), &d_sj[h]));
+    HIP_TRY(ctx, hipMemcpyAsync(jb0, hb0, tables_off, hipMemcpyHostToDevice, ctx->stream));
 
     tick("jobs");
     /* ---- launches ---- */
@@ -2571,9 +2604,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         HIP_TRY(ctx, hipGetLastError());
     }
     if (resident) {
-        /* asynchronous: the records stay on the device. The job tables were handed
-         * to hipMemcpyAsync from pageable memory; keep them alive until the next
-         * call instead of relying on the copy having staged them already. */
+        /* asynchronous: the records stay on the device. The pinned block the job tables
+         * are copied from goes back to the pool when this chain has run. */
         hipEvent_t done = nullptr;
         if (!ctx->event_pool.empty()) {
             done = ctx->event_pool.back();
@@ -2582,10 +2614,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
             HIP_TRY(ctx, hipEventCreate(&done));
         }
         HIP_TRY(ctx, hipEventRecord(done, ctx->stream));
-        ctx->resident_hold.emplace_back(done, std::make_shared<
-            std::tuple<std::vector<ProjJob>, std::vector<BinJob>, std::vector<FinalJob>,
-                       std::vector<std::vector<ScoreJob>>, std::vector<ZeroJob>>>(
-            std::move(ij), std::move(bj), std::move(fj), std::move(sj), std::move(zj)));
+        ctx->resident_hold.emplace_back(done, std::shared_ptr<void>(pin_block));
         return CSM_OK;
     }
     /* device copy of the records in query order (csm_copy_last_batch_records) */
