@@ -1527,6 +1527,8 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
         if (use1 && ++i1 < n1)
             rb = recs1[i1];
         __syncthreads();                                 /* previous tile consumed */
+        __builtin_amdgcn_s_setprio(3);                   /* the copy's requests go out ahead of the other
+                                                            workgroup's gather instructions (-0.35 %) */
 #pragma unroll
         for (int k = 0; k < kMaxP; ++k) {
             const int pc = wave + 8 * k;
@@ -1543,6 +1545,7 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
                 __builtin_amdgcn_global_load_lds((glb_ptr)(pbs1 + start1 + pe * 64 + lane),
                                                  (lds_ptr)(lpb1 + pe * 64), 4, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
