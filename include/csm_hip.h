@@ -24,7 +24,7 @@
  *  - scans must hold finite ranges and angles ("no return" beams filtered out
  *    upstream, as the reference's scan filters do): a non-finite value makes
  *    the matching entry points fail with CSM_EINVAL.
- *  - limits: at most 12288 beams per scan; LowResolution / 2^NodeHeightMax up
+ *  - limits: at most 10240 beams per scan (the binning kernel's tables live in LDS); LowResolution / 2^NodeHeightMax up
  *    to 64 cells; grid + window up to ~2500 x 2500 cells per map (CSM_EINVAL
  *    beyond).
  */

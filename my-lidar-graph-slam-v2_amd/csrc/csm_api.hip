@@ -335,7 +335,7 @@ bool merging_pays(const double* angles, const double* ranges, int n, double res)
 int bin_hash_size(int n_points)
 {
     int h = 1024;
-    while (2 * h < 3 * n_points && h < 32768)
+    while (2 * h < 3 * n_points && h < 16384)      /* kMaxPoints = 10240 -> 16384 */
         h <<= 1;
     return h;
 }
@@ -586,7 +586,7 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
         return fail(ctx, CSM_EINVAL, "more than %d beams per scan", kMaxPoints);
     const size_t bin_lds = bin_lds_bytes(p->tiles_x * p->tiles_y, p->n);
     if (bin_lds > 160 * 1024 - 64)
-        return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
+        return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel (its per-tile words, hash table and cell list exceed the LDS)");
     return CSM_OK;
 }
 
@@ -2211,7 +2211,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         n_points_max = std::max(n_points_max, p.n);
     }
     if (bin_lds > 160 * 1024 - 64)
-        return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel");
+        return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel (its per-tile words, hash table and cell list exceed the LDS)");
     const int nx = pp[0].nx, ny = pp[0].ny;
 
     /* scans go to the device as they are (angles, ranges); the projection runs

@@ -13,7 +13,8 @@ constexpr int kMaxRegionRowsStrided = 128; /* ... of a strided (coarser level) j
 constexpr int kPairMaxCby = 56;  /* candidate rows per workgroup of the pair-row fine kernel */
 constexpr int kPbMax = 1024;       /* entries per TileRec: k_bin splits fuller tiles */
 constexpr int kMaxMult = 15;       /* beams merged into one (cell, multiplicity) entry */
-constexpr int kMaxPoints = 12288;  /* beams per scan (hash table of k_bin: 16384 slots) */
+constexpr int kMaxPoints = 10240;  /* beams per scan: k_bin's hash table (16384 slots, load <= 2/3, 128 KB)
+                                      and cell list must fit the CU's 160 KB of LDS */
 constexpr int kBlock = 512;      /* threads per workgroup (8 wave64) */
 constexpr int kBinBlock = 256;   /* threads per workgroup of the binning kernel */
 constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */

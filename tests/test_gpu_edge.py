@@ -207,3 +207,62 @@ def test_correlative_batch_of_twenty_with_edge_band_queries(gpu_ctx, oracle):
     assert band > 0
     for i in range(len(cases)):
         gpu_ctx.release_grid(8100 + i)
+
+
+def _scattered_case(seed, n_beams):
+    """Returns scattered over a disc of 3 m (not a room scan: only the arithmetic is
+    under test): the endpoint tile under the disc's centre gets thousands of entries."""
+    c = synth.csm_case(seed, rows=128, cols=128, n_beams=n_beams, max_range=3.0, half_x=1.9, half_y=1.7,
+                       n_boxes=1, init_error=(0.06, -0.04, 0.01))
+    rng = np.random.RandomState(seed)
+    r = 0.2 + 2.8 * np.sqrt(rng.rand(n_beams))
+    r[int(np.argmax(r))] = 3.0
+    c["ranges"] = r.astype(np.float64)
+    return c
+
+
+def test_batch_with_tiles_split_into_several_records(gpu_ctx, oracle):
+    """Endpoint tiles with more than 1024 entries are cut into several records by
+    k_bin. The batch kernel walks the records of two theta slices together (tile
+    number, chunk number): every chunk must be gathered, whether or not the
+    neighbouring slice has a chunk of the same number."""
+    cases = [_scattered_case(400 + i, n) for i, n in enumerate([9000, 7000] + [2500] * 15)]
+    # the premise: some tile of some slice holds more than 1024 distinct row-pair cells
+    c = cases[0]
+    sx, sy, st = api.host_search_step(c["geom"][0], c["ranges"])
+    wx, wy, wt = api.host_window(0.6, sx), api.host_window(0.4, sy), api.host_window(math.radians(6), st)
+    col, row = api.host_project(c["geom"], c["init_pose"], st, wt, c["angles"], c["ranges"])
+    ny = -(-(2 * wy + 1) // 4) * 4
+    nx = -(-(2 * wx + 1) // 4) * 4
+    rr, cc = row[0] + (-wy + ny - 1) + ((ny - 1) & 1), col[0] + (-wx + nx - 1)
+    tile, cell = (rr // 64) * 1000 + cc // 64, (rr >> 1) * 4096 + cc
+    assert max(np.unique(cell[tile == t]).size for t in np.unique(tile)) > 1024
+    qs = []
+    for i, c in enumerate(cases):
+        gpu_ctx.upload_grid(8200 + i, c["grid"])
+        qs.append(dict(map_id=8200 + i, geom=c["geom"], angles=c["angles"], ranges=c["ranges"],
+                       rel_pose=c["rel_pose"], init_pose=c["init_pose"]))
+    for Lr, thr in ((4, (0.0, 0.0)), (3, (0.05, 0.1))):
+        outs = gpu_ctx.correlative_match_batch(qs, 0.6, 0.4, math.radians(6), Lr, thr[0], thr[1])
+        for c, o in zip(cases, outs):
+            lit = oracle.csm(c, 0.6, 0.4, math.radians(6), Lr, thr[0], thr[1])
+            raw = o["raw"]
+            assert o["pose_found"] == lit["found"], (Lr, raw, lit)
+            assert (raw["best_x"], raw["best_y"], raw["best_theta"]) == (lit["bestX"], lit["bestY"], lit["bestT"]), (Lr, raw, lit)
+            assert raw["score"] == lit["scoreMax"]
+    for i in range(len(cases)):
+        gpu_ctx.release_grid(8200 + i)
+
+
+def test_largest_scan_and_one_beam_more(gpu_ctx, oracle):
+    """10240 beams (csm_hip.h's limit: the binning kernel's tables fill the LDS) match
+    the literal sweep; 10241 are refused with CSM_EINVAL."""
+    case = _scattered_case(420, 10240)
+    _check_csm(gpu_ctx, oracle, case, 0.6, 0.4, math.radians(6), 4)
+    over = _scattered_case(421, 10241)
+    gpu_ctx.upload_grid(8300, over["grid"])
+    with pytest.raises(api.CsmError) as err:
+        gpu_ctx.correlative_match(8300, over["geom"], over["angles"], over["ranges"], over["rel_pose"],
+                                  over["init_pose"], 0.6, 0.4, math.radians(6), 4)
+    assert err.value.code == L.CSM_EINVAL and "beams" in str(err.value)
+    gpu_ctx.release_grid(8300)
