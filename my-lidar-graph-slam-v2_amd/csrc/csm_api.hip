@@ -444,8 +444,9 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
 /* The pair-row fine kernel (k_score_pairs<LS, 8, W>): LS = slots per pair row of
  * the LDS region = alignment column + 64-cell tile + cbx - 1 candidates, even
  * (16-byte rows for the LDS-DMA pieces). Instantiated for these LS; a candidate
- * block may be any width cbx <= LS - 65. */
-const int kPairLS[] = { 86, 98, 118, 130, 150, 162, 182 };
+ * block may be any width cbx <= LS - 65 (124: the conflict-free pitch of R = 6, cbx = 52,
+ * the branch-and-bound detector's default window). */
+const int kPairLS[] = { 86, 98, 118, 124, 130, 150, 162, 182 };
 
 size_t pair_lds_bytes(int ls, int cby, int lists)
 {
@@ -488,6 +489,16 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
             }
         if (!p.lstride)
             continue;
+        /* A half-wave that holds the end of one lane group and the start of the next
+         * reads without a bank conflict when the next group's slots continue the bank
+         * sequence: (R / 2) * LS = cbx (mod 32). Take such a pitch if one is instantiated
+         * within 8 slots of the smallest (0.9 % of the branch-and-bound leaf kernel; no
+         * even LS does it for R = 8, cbx = 84). */
+        for (int ls : kPairLS)
+            if (ls >= p.lstride && ls <= p.lstride + 8 && ((R / 2) * ls - p.cbx) % 32 == 0) {
+                p.lstride = ls;
+                break;
+            }
         int g = std::min(std::min(kBlock / p.cbx, ceil_div(ny, R)), kPairMaxCby / R);
         /* two workgroups per CU: at most 80 KB of LDS each */
         while (g > 1 && pair_lds_bytes(p.lstride, g * R, lists) > 80 * 1024)
@@ -686,7 +697,7 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
 #else
 #define PAIR_DISPATCH(CALL)                                                            \
     do {                                                                               \
-        PAIR_CASE(86, CALL) PAIR_CASE(98, CALL) PAIR_CASE(118, CALL)                   \
+        PAIR_CASE(86, CALL) PAIR_CASE(98, CALL) PAIR_CASE(118, CALL) PAIR_CASE(124, CALL) \
         PAIR_CASE(130, CALL) PAIR_CASE(150, CALL) PAIR_CASE(162, CALL)                 \
         PAIR_CASE(182, CALL)                                                           \
     } while (0)
