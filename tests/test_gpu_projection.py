@@ -89,3 +89,23 @@ def test_non_finite_ranges_are_rejected(gpu_ctx):
                                       1.0, 1.0, 0.2, 4)
         assert e.value.code == -22
         gpu_ctx.release_grid(4242)
+
+
+def test_non_finite_scan_in_a_large_batch_names_the_first_offender(gpu_ctx):
+    """Batches of >= 256 queries check their scans on several host threads: the
+    error must still name the FIRST bad query, and it comes before any map lookup."""
+    c = synth.csm_case(11, n_beams=360)
+    good_a, good_r = c["angles"], c["ranges"]
+    bad_nan, bad_inf = good_r.copy(), good_r.copy()
+    bad_nan[5] = float("nan")
+    bad_inf[300] = float("inf")
+    qs = []
+    for i in range(600):
+        r = bad_inf if i == 217 else bad_nan if i == 431 else good_r
+        qs.append(dict(map_id=990000 + i, geom=c["geom"], angles=good_a, ranges=r, rel_pose=c["rel_pose"],
+                       init_pose=c["init_pose"]))
+    for call in (lambda: gpu_ctx.bnb_match_batch(qs, 1.0, 1.0, 0.2, 2, 0.3, 0.5),
+                 lambda: gpu_ctx.correlative_match_batch(qs, 1.0, 1.0, 0.2, 4, 0.3, 0.5)):
+        with pytest.raises(api.CsmError) as e:
+            call()
+        assert e.value.code == -22 and "query 217" in str(e.value)
