@@ -469,8 +469,13 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
     const int max_cbx = kPairLS[sizeof(kPairLS) / sizeof(kPairLS[0]) - 1] - 65;
     /* R = candidate rows per lane: 8, or 6 where that covers the rows with fewer
      * multiply-adds per wave (52 rows: 9 groups x 6 instead of 7 x 8) */
+    const int force_r = getenv("CSM_PAIR_R") ? atoi(getenv("CSM_PAIR_R")) : 0;            /* tuning knobs */
+    const int force_ncbx = getenv("CSM_PAIR_NCBX") ? atoi(getenv("CSM_PAIR_NCBX")) : 0;
+    const int force_g = getenv("CSM_PAIR_GROUPS") ? atoi(getenv("CSM_PAIR_GROUPS")) : 0;
     for (int R : { 8, 6 })
     for (int ncbx = ceil_div(nx, max_cbx); ncbx <= ceil_div(nx, max_cbx) + 2; ++ncbx) {
+        if ((force_r && R != force_r) || (force_ncbx && ncbx != force_ncbx))
+            continue;
         PassPlan p;
         p.nx = nx;
         p.ny = ny;
@@ -500,19 +505,27 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
                 break;
             }
         int g = std::min(std::min(kBlock / p.cbx, ceil_div(ny, R)), kPairMaxCby / R);
-        /* two workgroups per CU: at most 80 KB of LDS each */
-        while (g > 1 && pair_lds_bytes(p.lstride, g * R, lists) > 80 * 1024)
+        /* two workgroups per CU: at most 80 KB of LDS each INCLUDING the kernel's static
+         * __shared__ arrays (a plan at exactly 80 KB of dynamic LDS ran one workgroup per
+         * CU: configs[4] took 87 ms instead of 56) */
+        while (g > 1 && pair_lds_bytes(p.lstride, g * R, lists) > 80 * 1024 - 1024)
             --g;
+        if (force_g && force_g <= g)
+            g = force_g;
         if (g < 1 || pair_lds_bytes(p.lstride, g * R, lists) > 160 * 1024 - 256)
             continue;
         p.ncby = ceil_div(ny, g * R);
-        g = ceil_div(ceil_div(ny, p.ncby), R);          /* balance the row blocks */
+        if (!force_g)
+            g = ceil_div(ceil_div(ny, p.ncby), R);      /* balance the row blocks */
         p.groups = g;
         /* per (block, tile): the window copy grows with the region; the gather costs
          * every wave R multiply-adds + ~6 other instructions per entry, however many
          * of its lanes are useful; ~450 cycles of barriers and waits */
         const double cost = (double)p.ncbx * p.ncby *
                             (0.01 * ((kTile + g * R) / 2 + 1) * p.lstride + 46.0 * (R + 6) + 450.0);
+        if (getenv("CSM_PLAN_DEBUG"))
+            fprintf(stderr, "[plan %dx%d] R %d ncbx %d cbx %d LS %d groups %d ncby %d lds %zu cost %.0f\n", nx, ny, R,
+                    ncbx, p.cbx, p.lstride, g, p.ncby, pair_lds_bytes(p.lstride, g * R, lists), cost);
         if (best < 0 || cost < best) {
             best = cost;
             *out = p;
