@@ -721,8 +721,8 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
         int rc_ = set_lds(ctx, k_score_pairs<LS, RR, WW>, lds);                        \
         if (rc_)                                                                       \
             return rc_;                                                                \
-        hipLaunchKernelGGL((k_score_pairs<LS, RR, WW>), grid, dim3(kBlock), lds, ctx->stream, \
-                           job, pp.cbx, pp.groups);                                    \
+        hipLaunchKernelGGL((k_score_pairs<LS, RR, WW>), theta_major ? dim3(grid.y, grid.x, 1) : grid, \
+                           dim3(kBlock), lds, ctx->stream, job, pp.cbx, pp.groups, theta_major); \
     } while (0)
 
 #define CALL_PAIRS_BATCH(LS, RR, WW)                                                   \
@@ -749,6 +749,10 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
     if (pp.pairs) {
         const size_t lds = pass_lds_bytes(pp);
         bool launched = false;
+        /* a launch far larger than the chip, not tile-split: slices fastest (see k_score_pairs) */
+        int theta_major = (n_slices == 1 && (long)pp.ncb() * n_theta >= 4096 && pp.ncb() <= 65535) ? 1 : 0;
+        if (const char* e = getenv("CSM_THETA_MAJOR"))
+            theta_major = (atoi(e) != 0 && n_slices == 1 && pp.ncb() <= 65535) ? 1 : 0;
         PAIR_DISPATCH(CALL_PAIRS_SINGLE);
         if (!launched)
             return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);

@@ -551,8 +551,8 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 template <int R>
 __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S)[R], uint32_t (&K)[R],
                                                int t, int bx, int by, int cbx, int cby, int g, int dxi,
-                                               bool lane_on, uint32_t qflags)
-{
+                                               bool lane_on, uint32_t qflags, int cb, int ncb)
+{   /* cb / ncb: this workgroup's candidate block and the blocks per slice (the record's slot) */
     __shared__ unsigned long long red_key[kBlock / 64];
     __shared__ unsigned long long red_rank[kBlock / 64];
     __shared__ uint32_t red_cnt[kBlock / 64];
@@ -695,7 +695,7 @@ __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S
         bb.rank = brank;
         bb.count = bcnt;
         bb.pad = 0;
-        job.block_best[(size_t)t * gridDim.x + blockIdx.x] = bb;
+        job.block_best[(size_t)t * ncb + cb] = bb;
     }
 }
 
@@ -974,7 +974,7 @@ __device__ __forceinline__ void score_body(const ScoreJob& job, int cbx, int gro
     }
     flush();
 
-    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags, (int)blockIdx.x, (int)gridDim.x);
 }
 
 /* grid = (candidate blocks, theta slices, tile slices) */
@@ -1087,16 +1087,15 @@ __global__ __launch_bounds__(256) void k_expand_pairs(const uint16_t* __restrict
  * Entries arrive sorted by class, TileRec.pad = class counts. */
 template <int LS, int R, bool WEIGHTED>
 __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, int groups, int slice,
-                                                 int n_slices)
+                                                 int n_slices, int t, int cb, int ncb)
 {
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
-    const int t = blockIdx.y;
     if (t >= job.n_theta)
         return;
     const int tid = threadIdx.x;
     const int ncbx = (job.nx + cbx - 1) / cbx;
-    const int bx = blockIdx.x % ncbx, by = blockIdx.x / ncbx;
+    const int bx = cb % ncbx, by = cb / ncbx;
     const int cby = groups * R;
     if (by * cby >= job.ny)
         return;
@@ -1300,7 +1299,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         run(cnt, std::integral_constant<int, 2>());
     }
     flush();
-    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags, cb, ncb);
 }
 
 /* ---- two theta slices per workgroup ---------------------------------------
@@ -1563,24 +1562,34 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
         S1[r] += acc1[r] & 0x7fffffu;
         K1[r] += acc1[r] >> 23;
     }
-    score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+    score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags, (int)blockIdx.x, (int)gridDim.x);
     if (two) {
         __syncthreads();                                 /* the epilogue's reduction arrays */
-        score_epilogue<R>(job, S1, K1, t1, bx, by, cbx, cby, g, dxi, lane_on, qflags);
+        score_epilogue<R>(job, S1, K1, t1, bx, by, cbx, cby, g, dxi, lane_on, qflags, (int)blockIdx.x, (int)gridDim.x);
     }
 }
 
+/* grid = (candidate blocks, theta slices, tile slices), or with theta_major
+ * (theta slices, candidate blocks, 1): the workgroups that run at the same time then
+ * belong to ONE candidate block and neighbouring slices and copy (nearly) the same
+ * windows of the map -- for maps far larger than an L2 (configs[4]: 56 MB) that turns
+ * the window copies from fabric traffic into L2 hits. */
 template <int LS, int R, bool WEIGHTED>
-__global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups)
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups, int theta_major)
 {
-    score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z);
+    if (theta_major)
+        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+    else
+        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, (int)blockIdx.y,
+                                          (int)blockIdx.x, (int)gridDim.x);
 }
 
 /* grid = (candidate blocks, theta slices, jobs) */
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups)
 {
-    score_body_pairs<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, 0, 1);
+    score_body_pairs<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, 0, 1, (int)blockIdx.y, (int)blockIdx.x,
+                                      (int)gridDim.x);
 }
 
 /* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
