@@ -5,7 +5,7 @@ N = 1 (default): BASELINE.json configs[1] -- frontend CSM, 1080-beam scan over
 270 deg, 400x400 grid @ 5 cm, +-2 m / +-30 deg window at 5 cm / 0.5 deg, L = 4
 (123 x 84 x 84 = 867,888 candidate poses per scan, 2160 algorithmic bytes
 each). One step = SCANS_PER_STEP (3072) scans, hit indices and grid already
-resident in HBM, scored 64 windows per batched launch chain
+resident in HBM, scored 256 windows per batched launch chain
 (csm_score_windows_dev), so that the K timed steps last seconds, not
 milliseconds. The same line carries, under "configs", short driver-timed runs
 of configs[2] (256 submaps, pyramid build reported separately), configs[3] at
@@ -43,9 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "my-lidar-graph-slam-v2_amd"))
 
-WINDOWS_PER_LAUNCH = 64
+WINDOWS_PER_LAUNCH = int(os.environ.get("CSM_BENCH_WINDOWS", "256"))   # scans per batched launch chain
 SCANS_PER_STEP = int(os.environ.get("CSM_BENCH_SCANS", "3072"))     # scans per step
-DISTINCT_SCANS = int(os.environ.get("CSM_BENCH_DISTINCT", "256"))    # different scans generated
+DISTINCT_SCANS = int(os.environ.get("CSM_BENCH_DISTINCT", "512"))    # different scans generated
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # MI355X_MICROARCH.md, LDS: 64 banks x 4 B per clock per CU (ds_read_b64 / b128
 # rate), 256 CUs, 2.4 GHz max clock. ds_read_b32 reaches half of it.
@@ -108,7 +108,12 @@ def pmc_traffic(path=None):
         src = "%s (committed; kernel %s, %s windows per launch, library %s)" % (
             os.path.relpath(path, ROOT), d.get("kernel", "?"), d.get("windows_per_launch", "?"),
             d.get("library_version", "?"))
-        return float(d["hbm_bytes_per_launch"]), src
+        scale = 1.0
+        wpl = d.get("windows_per_launch")
+        if path == PMC_FILE and isinstance(wpl, int) and wpl > 0 and wpl != WINDOWS_PER_LAUNCH:
+            scale = WINDOWS_PER_LAUNCH / float(wpl)
+            src += "; scaled to %d windows per launch" % WINDOWS_PER_LAUNCH
+        return float(d["hbm_bytes_per_launch"]) * scale, src
     except (OSError, KeyError, ValueError):
         return None, None
 

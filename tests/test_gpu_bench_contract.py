@@ -38,7 +38,7 @@ def _check_roofline(r):
 
 def test_default_line():
     d = _run("--steps", "2", "--warmup", "1",
-             env={"CSM_BENCH_SCANS": "256", "CSM_BENCH_DISTINCT": "128",
+             env={"CSM_BENCH_SCANS": "256", "CSM_BENCH_DISTINCT": "128", "CSM_BENCH_WINDOWS": "64",
                   "CSM_BENCH_CONFIGS": "config2_single_query,config3,config5"})
     for k in REQUIRED:
         assert k in d, k
@@ -108,6 +108,6 @@ def test_two_rank_rehearsal_csm_replicas():
     """--workload csm at N > 1: configs[1] per rank + all-gather of the per-scan
     records; bench.py asserts that the gathered slice of every rank equals the
     records it wrote (the ordering of the collective against the scoring stream)."""
-    d = _two_ranks(29534, "--workload", "csm", env={"CSM_BENCH_SCANS": "128", "CSM_BENCH_DISTINCT": "64"})
+    d = _two_ranks(29534, "--workload", "csm", env={"CSM_BENCH_SCANS": "128", "CSM_BENCH_DISTINCT": "64", "CSM_BENCH_WINDOWS": "64"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["poses_found"] == 128

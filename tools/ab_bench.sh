@@ -3,6 +3,7 @@
 # environment, alternating, on the box this runs on (A/B only means something on one box in one call).
 cd "$(dirname "$0")/.."
 export CSM_BENCH_SCANS=${CSM_BENCH_SCANS:-512}
+export CSM_BENCH_WINDOWS=${CSM_BENCH_WINDOWS:-64}     # A/B numbers are per 64-window launch
 for rep in 1 2; do
   for spec in "$@"; do
     v="${spec%%:*}"; envs=""

@@ -24,15 +24,15 @@ run_pmc() {     # name, counter, bench args...
 
 # configs[1], the default line
 run_stats csm --no-configs --no-cpu-baseline || exit 1
-export CSM_BENCH_SCANS=256 CSM_BENCH_DISTINCT=64
+export CSM_BENCH_SCANS=512 CSM_BENCH_DISTINCT=256
 run_pmc csm FETCH_SIZE --steps 3 --warmup 1 --no-configs --no-cpu-baseline || exit 1
 run_pmc csm WRITE_SIZE --steps 3 --warmup 1 --no-configs --no-cpu-baseline || exit 1
 # configs[4]: the one workload whose maps leave L2 (56 MB pair-row copy, 8 MB grid)
-export CSM_BENCH_SCANS=64 CSM_BENCH_CONFIGS=config5
+export CSM_BENCH_SCANS=64 CSM_BENCH_WINDOWS=64 CSM_BENCH_CONFIGS=config5
 run_stats cfg5 --steps 1 --warmup 1 --no-cpu-baseline || exit 1
 run_pmc cfg5 FETCH_SIZE --steps 1 --warmup 1 --no-cpu-baseline || exit 1
 run_pmc cfg5 WRITE_SIZE --steps 1 --warmup 1 --no-cpu-baseline || exit 1
-unset CSM_BENCH_SCANS CSM_BENCH_DISTINCT CSM_BENCH_CONFIGS
+unset CSM_BENCH_SCANS CSM_BENCH_DISTINCT CSM_BENCH_CONFIGS CSM_BENCH_WINDOWS
 # configs[2]: the branch-and-bound batch
 run_stats loop --workload loop --steps 10 --no-cpu-baseline || exit 1
 
@@ -51,7 +51,7 @@ def counters(name):
                 d = acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], [0.0, 0])
                 d[0] += float(row["Counter_Value"]); d[1] += 1
     return {k: {c: {"mean_KB": s / n, "dispatches": n} for c, (s, n) in v.items()} for k, v in acc.items()}
-for name, pick, wpl in (("csm", "_batch<", 64), ("cfg5", "k_score_pairs<", 1)):
+for name, pick, wpl in (("csm", "_batch<", int(os.environ.get("CSM_BENCH_WINDOWS", "256"))), ("cfg5", "k_score_pairs<", 1)):
     per = counters(name)
     dom = [k for k in per if pick in k and "k_score_pairs" in k]
     if name == "cfg5":      # the 2000x2000 query's kernel: the single-window pair kernel with the widest rows

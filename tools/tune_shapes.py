@@ -10,7 +10,7 @@ which = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = dict(os.environ)
 if which == "config2":
-    args, env0 = ["--no-configs", "--no-cpu-baseline", "--steps", "3"], {"CSM_BENCH_SCANS": "512"}
+    args, env0 = ["--no-configs", "--no-cpu-baseline", "--steps", "3"], {"CSM_BENCH_SCANS": "512", "CSM_BENCH_WINDOWS": "64"}
     shapes = [(r, n, g) for r in (8, 6) for n in (1, 2, 3) for g in (0,)]
     pick = lambda d: (d["roofline"]["avg_launch_us"], d["ms_per_step"])
 elif which == "loop":
@@ -18,7 +18,7 @@ elif which == "loop":
     shapes = [(r, n, g) for r in (8, 6) for n in (1, 2) for g in (0,)]
     pick = lambda d: (d["roofline"]["avg_launch_us"], d["ms_per_step"])
 else:
-    args, env0 = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"], {"CSM_BENCH_SCANS": "64", "CSM_BENCH_CONFIGS": "config5"}
+    args, env0 = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"], {"CSM_BENCH_SCANS": "64", "CSM_BENCH_WINDOWS": "64", "CSM_BENCH_CONFIGS": "config5"}
     shapes = [(r, n, g) for r in (8, 6) for n in (7, 8, 9) for g in (0,)]
     pick = lambda d: (d["configs"]["config5"]["roofline"]["avg_launch_us"], d["configs"]["config5"]["ms_per_query"])
 for r, n, g in [(0, 0, 0)] + shapes:
