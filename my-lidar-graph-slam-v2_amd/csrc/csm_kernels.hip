@@ -2055,7 +2055,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_pick(GridSearchJob job)
 }
 
 /* ------------------------------------------------------------------ batch */
-__global__ __launch_bounds__(kBinBlock) void k_bin_batch(const BinJob* jobs)
+__global__ __launch_bounds__(kBinBlock, 8) void k_bin_batch(const BinJob* jobs)
 {
     /* k_bin reads blockIdx.x as the theta slice */
     k_bin_body(jobs[blockIdx.y]);
