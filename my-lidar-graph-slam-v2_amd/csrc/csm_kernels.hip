@@ -487,7 +487,7 @@ __device__ __forceinline__ void k_bin_body(const BinJob& job)
 #endif
 }
 
-__global__ __launch_bounds__(kBinBlock) void k_bin(BinJob job)
+__global__ __launch_bounds__(kBinBlock, 8) void k_bin(BinJob job)
 {
     k_bin_body(job);
 }
