@@ -1113,6 +1113,11 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     const int tb = lane_on ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    /* a wave none of whose lanes owns a candidate inside the window (the last row block
+     * of 84 rows in blocks of 48: rows 88..95) copies windows and keeps the barriers,
+     * but gathers nothing */
+    const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
+                                                       by * cby + g * R < job.ny) != 0;
 
     uint32_t S[R], K[R], acc[R];
 #pragma unroll
@@ -1294,9 +1299,11 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
                     pb_cur = lpb[j + lane];
             }
         };
-        run(end_both, std::integral_constant<int, 0>());
-        run(end_even, std::integral_constant<int, 1>());
-        run(cnt, std::integral_constant<int, 2>());
+        if (wave_live) {
+            run(end_both, std::integral_constant<int, 0>());
+            run(end_even, std::integral_constant<int, 1>());
+            run(cnt, std::integral_constant<int, 2>());
+        }
     }
     flush();
     score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags, cb, ncb);
@@ -1455,6 +1462,9 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     const int tb = lane_on ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    /* see score_body_pairs: waves without a candidate inside the window do not gather */
+    const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
+                                                       by * cby + g * R < job.ny) != 0;
 
     uint32_t S0[R], K0[R], acc0[R], S1[R], K1[R], acc1[R];
 #pragma unroll
@@ -1548,10 +1558,10 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
-        if (cnt0 > 0)
+        if (wave_live && cnt0 > 0)
             pairs_gather<LS, R, WEIGHTED>(lane_addr + (uint32_t)shift0, lpb0, lane, cnt0, cls0 & 0xffff,
                                           (cls0 & 0xffff) + (cls0 >> 16), acc0, S0, K0, pending0);
-        if (cnt1 > 0)
+        if (wave_live && cnt1 > 0)
             pairs_gather<LS, R, WEIGHTED>(lane_addr + (uint32_t)shift1, lpb1, lane, cnt1, cls1 & 0xffff,
                                           (cls1 & 0xffff) + (cls1 >> 16), acc1, S1, K1, pending1);
     }
