@@ -1071,6 +1071,175 @@ __global__ __launch_bounds__(256) void k_expand_pairs(const uint16_t* __restrict
     }
 }
 
+/* Inclusive prefix sum over the wave's 64 lanes, data-parallel primitives only (no LDS
+ * traffic: the gather counts its own LDS reads in lgkmcnt). */
+__device__ __forceinline__ int wave_prefix_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);       /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);       /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);       /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);       /* row_shr:8 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);       /* row_bcast:15 -> rows 1, 3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);       /* row_bcast:31 -> rows 2, 3 */
+    return x;
+}
+
+/* When the packed accumulators (value sum in 23 bits, known count above) must be emptied.
+ * They hold 128 beams. Counting beams per group of entries cost ten scalar instructions per
+ * group (7 % of the kernel); instead the 64 entries of a chunk of the list are looked at
+ * once, one entry per lane: C = beams gathered so far including the entry (a running count
+ * modulo 96 + a prefix sum). An entry is FLAGGED if C crosses a multiple of 96 at it, if it
+ * is heavy (more than 8 beams), or if one of the four entries before it is heavy; a group
+ * that holds a flagged entry empties the accumulators first. Between two flushes lie one
+ * flagged group and groups without a flagged entry. If the flagged group has a heavy entry,
+ * the next group is flagged too: <= 4 x 30 beams. Otherwise it has <= 32 beams and the
+ * others stay inside one bucket of 96 (< 96 beams): < 128 in all. */
+struct FlushState {
+    int cum;        /* beams gathered so far, modulo 96 */
+    int carry;      /* a heavy entry among the last four of the previous chunk */
+};
+
+/* After the last record: the accumulators' rest, then the value sum alone
+ * (S held sum + count << 23 modulo 2^32; the sum itself is below 2^27). */
+template <int R>
+__device__ __forceinline__ void pairs_finish(uint32_t (&acc)[R], uint32_t (&S)[R], uint32_t (&K)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        K[r] += acc[r] >> 23;
+        S[r] = S[r] + acc[r] - (K[r] << 23);
+    }
+}
+
+/* The entries of one slice's record from the staged window; the rules of the hand-issued
+ * reads: a read must reach its lds_wait without crossing a loop edge (a register copy the
+ * compiler places on an edge would copy the register before the data has landed), so the
+ * pipeline drains at the end of every group of four entries. One entry: `pbv` =
+ * m_odd << 28 | m_even << 24 | beams << 19 | byte offset of its first slot. CLS 0: both rows
+ * hit, 1: even row only, 2: odd row only. The reads are hand-issued ds_read_b64 (the compiler
+ * would fuse two of them into a ds_read2_b64, which runs at half the rate). */
+template <int LS, int R, bool WEIGHTED>
+__device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t* lpb, int lane, int cnt,
+                                             int end_both, int end_even, uint32_t (&acc)[R],
+                                             uint32_t (&S)[R], uint32_t (&K)[R], FlushState& fs)
+{
+    constexpr int kRowBytes = LS * 8;
+    /* S collects the whole packed word (value sum + known count << 23, modulo 2^32), K the
+     * count; pairs_finish() takes the count back out. One instruction per row less than
+     * splitting the word here (the flushes are 6 % of the kernel). */
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S[r] += acc[r];
+            K[r] += acc[r] >> 23;
+            acc[r] = 0;
+        }
+    };
+    auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
+        constexpr int CLS = decltype(cls)::value;
+        const uint32_t addr = lane_addr + (pbv & 0x7ffffu);
+        lds_read_b64<0 * kRowBytes>(addr, q[0]);
+        lds_read_b64<1 * kRowBytes>(addr, q[1]);
+        if (R >= 6)
+            lds_read_b64<2 * kRowBytes>(addr, q[2]);
+        if (R >= 8)
+            lds_read_b64<3 * kRowBytes>(addr, q[3]);
+        if (CLS != 1)
+            lds_read_b64<(R / 2) * kRowBytes>(addr, q[R / 2]);
+    };
+    auto mads = [&](uint32_t pbv, auto cls, const unsigned long long (&q)[R / 2 + 1]) {
+        constexpr int CLS = decltype(cls)::value;
+        uint32_t v[R + 2];
+#pragma unroll
+        for (int i = 0; i < R / 2 + 1; ++i) {
+            v[2 * i] = (uint32_t)q[i];
+            v[2 * i + 1] = (uint32_t)(q[i] >> 32);
+        }
+        const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
+        if (WEIGHTED) {
+            /* the two multiply-adds of one accumulator are kept R instructions
+             * apart: back to back the compiler pads them with s_nop */
+            if (CLS != 2) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r] = mad_u24(v[r], me, acc[r]);
+            }
+            if (CLS != 1) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r] = mad_u24(v[r + 1], mo, acc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (CLS == 0)
+                    acc[r] += v[r] + v[r + 1];       /* v_add3_u32 */
+                else
+                    acc[r] += v[CLS == 1 ? r : r + 1];
+            }
+        }
+    };
+    /* 64 entries of the list, one per lane, and their flush flags */
+    uint32_t pb_cur;
+    unsigned long long flags;
+    auto load_chunk = [&](int j0) {
+        pb_cur = lpb[j0 + lane];
+        const int b = j0 + lane < cnt ? (int)((pb_cur >> 19) & 31u) : 0;
+        const int c1 = fs.cum + wave_prefix_sum(b), c0 = c1 - b;        /* < 96 + 64 * 30 */
+        const bool cross = ((uint32_t)c1 * 683u) >> 16 != ((uint32_t)c0 * 683u) >> 16;   /* floor(c / 96), c < 2900 */
+        const unsigned long long heavy = __builtin_amdgcn_ballot_w64(b > 8);
+        flags = __builtin_amdgcn_ballot_w64(cross) | heavy | heavy << 1 | heavy << 2 | heavy << 3 | heavy << 4 |
+                (fs.carry ? 0xfull : 0ull);
+        fs.carry = (heavy >> 60) != 0;
+        fs.cum = __builtin_amdgcn_readlane(c1, 63) % 96;
+    };
+    int j = 0;
+    load_chunk(0);
+    auto run = [&](int end, auto cls) {
+        constexpr int CLS = decltype(cls)::value;
+        constexpr int NP = CLS == 1 ? R / 2 : R / 2 + 1;     /* reads per entry */
+        constexpr int NQ = R / 2 + 1;
+        while (j < end) {
+            const int stop = min(end, (j | 63) + 1);
+            for (; j + 4 <= stop; j += 4) {
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
+                const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
+                const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
+                if ((flags >> (j & 63)) & 0xfull)
+                    flush();
+                unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ];
+                issue(o0, cls, qa);
+                issue(o1, cls, qb);
+                lds_wait<NP, NQ>(qa);                 /* all but the NP reads just issued */
+                mads(o0, cls, qa);
+                issue(o2, cls, qc);
+                lds_wait<NP, NQ>(qb);
+                mads(o1, cls, qb);
+                issue(o3, cls, qd);
+                lds_wait<NP, NQ>(qc);
+                mads(o2, cls, qc);
+                lds_wait<0, NQ>(qd);
+                mads(o3, cls, qd);
+            }
+            for (; j < stop; ++j) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+                if ((flags >> (j & 63)) & 1ull)
+                    flush();
+                unsigned long long qa[NQ];
+                issue(o, cls, qa);
+                lds_wait<0, NQ>(qa);
+                mads(o, cls, qa);
+            }
+            if ((j & 63) == 0 && j < cnt)
+                load_chunk(j);
+        }
+    };
+    run(end_both, std::integral_constant<int, 0>());
+    run(end_even, std::integral_constant<int, 1>());
+    run(cnt, std::integral_constant<int, 2>());
+}
+
 /* The fine level (candidates one cell apart) with the LDS region stored in
  * ROW PAIRS: the 8-byte slot (pair row k, column c) holds the expanded cells of
  * region rows 2k and 2k + 1 at column c. A lane owns one candidate column and R
@@ -1126,16 +1295,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         K[r] = 0;
         acc[r] = 0;
     }
-    int pending = 0;
-    auto flush = [&]() {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            S[r] += acc[r] & 0x7fffffu;
-            K[r] += acc[r] >> 23;
-            acc[r] = 0;
-        }
-        pending = 0;
-    };
+    FlushState fs = { 0, 0 };
 
     const int ntiles = job.in_s ? 0 : job.n_tiles[t];
     const TileRec* recs = job.tiles + (size_t)t * job.max_tiles;
@@ -1197,115 +1357,11 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        /* One entry: `pbv` = m_odd << 28 | m_even << 24 | beams << 19 | byte offset of its
-         * first slot. CLS 0: both rows hit, 1: even row only, 2: odd row only. The reads
-         * are hand-issued ds_read_b64 (the compiler would fuse two of them into a
-         * ds_read2_b64, which runs at half the rate). */
         const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
-        auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
-            constexpr int CLS = decltype(cls)::value;
-            const uint32_t addr = lane_addr + (pbv & 0x7ffffu);
-            lds_read_b64<0 * kRowBytes>(addr, q[0]);
-            lds_read_b64<1 * kRowBytes>(addr, q[1]);
-            if (R >= 6)
-                lds_read_b64<2 * kRowBytes>(addr, q[2]);
-            if (R >= 8)
-                lds_read_b64<3 * kRowBytes>(addr, q[3]);
-            if (CLS != 1)
-                lds_read_b64<(R / 2) * kRowBytes>(addr, q[R / 2]);
-        };
-        auto mads = [&](uint32_t pbv, auto cls, const unsigned long long (&q)[R / 2 + 1]) {
-            constexpr int CLS = decltype(cls)::value;
-            uint32_t v[R + 2];
-#pragma unroll
-            for (int i = 0; i < R / 2 + 1; ++i) {
-                v[2 * i] = (uint32_t)q[i];
-                v[2 * i + 1] = (uint32_t)(q[i] >> 32);
-            }
-            const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
-            if (WEIGHTED) {
-                /* the two multiply-adds of one accumulator are kept R instructions
-                 * apart: back to back the compiler pads them with s_nop */
-                if (CLS != 2) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[r] = mad_u24(v[r], me, acc[r]);
-                }
-                if (CLS != 1) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[r] = mad_u24(v[r + 1], mo, acc[r]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (CLS == 0)
-                        acc[r] += v[r] + v[r + 1];       /* v_add3_u32 */
-                    else
-                        acc[r] += v[CLS == 1 ? r : r + 1];
-                }
-            }
-        };
-        auto beams_of = [&](uint32_t pbv) { return (int)((pbv >> 19) & 31u); };
-        /* Entries [j, end) of one class; 64 entries per LDS read of the list,
-         * broadcast with v_readlane. Four entries per group, straight-line: a
-         * hand-issued read must reach its lds_wait without crossing a loop edge
-         * (a register copy the compiler places on an edge would copy the
-         * register before the data has landed), so the pipeline drains at the
-         * end of every group. */
-        int j = 0;
-        uint32_t pb_cur = lpb[lane];
-        auto run = [&](int end, auto cls) {
-            constexpr int CLS = decltype(cls)::value;
-            constexpr int NP = CLS == 1 ? R / 2 : R / 2 + 1;     /* reads per entry */
-            constexpr int NQ = R / 2 + 1;
-            while (j < end) {
-                const int stop = min(end, (j | 63) + 1);
-                for (; j + 4 <= stop; j += 4) {
-                    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
-                    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
-                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
-                    const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
-                    const int mm = beams_of(o0) + beams_of(o1) + beams_of(o2) + beams_of(o3);
-                    if (pending + mm > 128)
-                        flush();
-                    pending += mm;
-                    unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ];
-                    issue(o0, cls, qa);
-                    issue(o1, cls, qb);
-                    lds_wait<NP, NQ>(qa);                 /* all but the NP reads just issued */
-                    mads(o0, cls, qa);
-                    issue(o2, cls, qc);
-                    lds_wait<NP, NQ>(qb);
-                    mads(o1, cls, qb);
-                    issue(o3, cls, qd);
-                    lds_wait<NP, NQ>(qc);
-                    mads(o2, cls, qc);
-                    lds_wait<0, NQ>(qd);
-                    mads(o3, cls, qd);
-                }
-                for (; j < stop; ++j) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
-                    const int mm = beams_of(o);
-                    if (pending + mm > 128)
-                        flush();
-                    pending += mm;
-                    unsigned long long qa[NQ];
-                    issue(o, cls, qa);
-                    lds_wait<0, NQ>(qa);
-                    mads(o, cls, qa);
-                }
-                if ((j & 63) == 0 && j < cnt)
-                    pb_cur = lpb[j + lane];
-            }
-        };
-        if (wave_live) {
-            run(end_both, std::integral_constant<int, 0>());
-            run(end_even, std::integral_constant<int, 1>());
-            run(cnt, std::integral_constant<int, 2>());
-        }
+        if (wave_live)
+            pairs_gather<LS, R, WEIGHTED>(lane_addr, lpb, lane, cnt, end_both, end_even, acc, S, K, fs);
     }
-    flush();
+    pairs_finish<R>(acc, S, K);
     score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags, cb, ncb);
 }
 
@@ -1317,117 +1373,6 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
  * two bounding boxes -- and gathers the entries of both slices from it into two
  * sets of accumulators: the barriers, the DMA wait and the window copy of a tile
  * are paid once per two slices (they were 29 % + 6 % of the single-slice kernel). */
-
-/* The entries of one slice's record from the staged window: exactly the gather of
- * score_body_pairs (see there for the rules of the hand-issued reads). */
-template <int LS, int R, bool WEIGHTED>
-__device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t* lpb, int lane, int cnt,
-                                             int end_both, int end_even, uint32_t (&acc)[R],
-                                             uint32_t (&S)[R], uint32_t (&K)[R], int& pending)
-{
-    constexpr int kRowBytes = LS * 8;
-    auto flush = [&]() {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            S[r] += acc[r] & 0x7fffffu;
-            K[r] += acc[r] >> 23;
-            acc[r] = 0;
-        }
-        pending = 0;
-    };
-    auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
-        constexpr int CLS = decltype(cls)::value;
-        const uint32_t addr = lane_addr + (pbv & 0x7ffffu);
-        lds_read_b64<0 * kRowBytes>(addr, q[0]);
-        lds_read_b64<1 * kRowBytes>(addr, q[1]);
-        if (R >= 6)
-            lds_read_b64<2 * kRowBytes>(addr, q[2]);
-        if (R >= 8)
-            lds_read_b64<3 * kRowBytes>(addr, q[3]);
-        if (CLS != 1)
-            lds_read_b64<(R / 2) * kRowBytes>(addr, q[R / 2]);
-    };
-    auto mads = [&](uint32_t pbv, auto cls, const unsigned long long (&q)[R / 2 + 1]) {
-        constexpr int CLS = decltype(cls)::value;
-        uint32_t v[R + 2];
-#pragma unroll
-        for (int i = 0; i < R / 2 + 1; ++i) {
-            v[2 * i] = (uint32_t)q[i];
-            v[2 * i + 1] = (uint32_t)(q[i] >> 32);
-        }
-        const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
-        if (WEIGHTED) {
-            if (CLS != 2) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    acc[r] = mad_u24(v[r], me, acc[r]);
-            }
-            if (CLS != 1) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    acc[r] = mad_u24(v[r + 1], mo, acc[r]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (CLS == 0)
-                    acc[r] += v[r] + v[r + 1];
-                else
-                    acc[r] += v[CLS == 1 ? r : r + 1];
-            }
-        }
-    };
-    auto beams_of = [&](uint32_t pbv) { return (int)((pbv >> 19) & 31u); };
-    int j = 0;
-    uint32_t pb_cur = lpb[lane];
-    auto run = [&](int end, auto cls) {
-        constexpr int CLS = decltype(cls)::value;
-        constexpr int NP = CLS == 1 ? R / 2 : R / 2 + 1;
-        constexpr int NQ = R / 2 + 1;
-        while (j < end) {
-            const int stop = min(end, (j | 63) + 1);
-            for (; j + 4 <= stop; j += 4) {
-                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
-                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
-                const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
-                const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
-                const int mm = beams_of(o0) + beams_of(o1) + beams_of(o2) + beams_of(o3);
-                if (pending + mm > 128)
-                    flush();
-                pending += mm;
-                unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ];
-                issue(o0, cls, qa);
-                issue(o1, cls, qb);
-                lds_wait<NP, NQ>(qa);
-                mads(o0, cls, qa);
-                issue(o2, cls, qc);
-                lds_wait<NP, NQ>(qb);
-                mads(o1, cls, qb);
-                issue(o3, cls, qd);
-                lds_wait<NP, NQ>(qc);
-                mads(o2, cls, qc);
-                lds_wait<0, NQ>(qd);
-                mads(o3, cls, qd);
-            }
-            for (; j < stop; ++j) {
-                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
-                const int mm = beams_of(o);
-                if (pending + mm > 128)
-                    flush();
-                pending += mm;
-                unsigned long long qa[NQ];
-                issue(o, cls, qa);
-                lds_wait<0, NQ>(qa);
-                mads(o, cls, qa);
-            }
-            if ((j & 63) == 0 && j < cnt)
-                pb_cur = lpb[j + lane];
-        }
-    };
-    run(end_both, std::integral_constant<int, 0>());
-    run(end_even, std::integral_constant<int, 1>());
-    run(cnt, std::integral_constant<int, 2>());
-}
 
 template <int LS, int R, bool WEIGHTED>
 __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups)
@@ -1470,7 +1415,7 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
 #pragma unroll
     for (int r = 0; r < R; ++r)
         S0[r] = K0[r] = acc0[r] = S1[r] = K1[r] = acc1[r] = 0;
-    int pending0 = 0, pending1 = 0;
+    FlushState fs0 = { 0, 0 }, fs1 = { 0, 0 };
 
     const bool gather = !job.in_s;
     const int n0 = __builtin_amdgcn_readfirstlane(gather ? job.n_tiles[t0] : 0);
@@ -1560,18 +1505,13 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
         const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
         if (wave_live && cnt0 > 0)
             pairs_gather<LS, R, WEIGHTED>(lane_addr + (uint32_t)shift0, lpb0, lane, cnt0, cls0 & 0xffff,
-                                          (cls0 & 0xffff) + (cls0 >> 16), acc0, S0, K0, pending0);
+                                          (cls0 & 0xffff) + (cls0 >> 16), acc0, S0, K0, fs0);
         if (wave_live && cnt1 > 0)
             pairs_gather<LS, R, WEIGHTED>(lane_addr + (uint32_t)shift1, lpb1, lane, cnt1, cls1 & 0xffff,
-                                          (cls1 & 0xffff) + (cls1 >> 16), acc1, S1, K1, pending1);
+                                          (cls1 & 0xffff) + (cls1 >> 16), acc1, S1, K1, fs1);
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        S0[r] += acc0[r] & 0x7fffffu;
-        K0[r] += acc0[r] >> 23;
-        S1[r] += acc1[r] & 0x7fffffu;
-        K1[r] += acc1[r] >> 23;
-    }
+    pairs_finish<R>(acc0, S0, K0);
+    pairs_finish<R>(acc1, S1, K1);
     score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags, (int)blockIdx.x, (int)gridDim.x);
     if (two) {
         __syncthreads();                                 /* the epilogue's reduction arrays */

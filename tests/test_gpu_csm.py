@@ -88,3 +88,25 @@ def test_beam_merging_on_and_off_give_identical_sums(gpu_ctx, oracle, merge_mode
     assert (res["best_x"], res["best_y"], res["best_theta"]) == (lit["bestX"], lit["bestY"], lit["bestT"])
     assert res["score"] == lit["scoreMax"]
     gpu_ctx.release_grid(2)
+
+
+@pytest.mark.parametrize("n_beams,max_range,merge_mode", [(4000, 1.2, 0), (4000, 1.2, 1), (1080, 5.7, 0),
+                                                           (2000, 0.3, 0)])
+def test_saturated_grid_never_overflows_the_packed_accumulators(gpu_ctx, oracle, n_beams, max_range, merge_mode):
+    """The fine kernel adds value and known count of a gather in one 32-bit
+    multiply-add (23 + 9 bits) and empties those accumulators by a rule over the
+    entry list (flags per 64-entry chunk: pairs_gather). Every cell at 65535 and
+    many beams per cell (entries of up to 30 beams) is the worst case for it:
+    any stretch of more than 128 beams between two flushes corrupts K."""
+    case = synth.csm_case(17, n_beams=n_beams, max_range=max_range)
+    case["grid"] = np.full_like(case["grid"], 65535)
+    rx, ry, rt, L = 0.8, 0.8, math.radians(6), 4
+    (wx, wy, wt), col, row, mk = _window_for(case, rx, ry, rt, L)
+    gpu_ctx.upload_grid(3, case["grid"])
+    gpu_ctx.build_pyramid(3, [1, L])
+    w = gpu_ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, L, 1, mk, 0.0, merge_mode)
+    res, S, K, CK = gpu_ctx.score_window(3, w, col, row, dump=True)
+    want, oS, oK, oCK = oracle.csm_closed_form(case, rx, ry, rt, L, dump=True)
+    assert np.array_equal(K, oK) and np.array_equal(S, oS)
+    assert int(K.max()) == n_beams and int(S.max()) == 65535 * n_beams
+    gpu_ctx.release_grid(3)
