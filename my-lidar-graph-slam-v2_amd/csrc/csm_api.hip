@@ -102,6 +102,7 @@ struct csm_ctx {
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
+    std::map<std::array<int, 4>, uint16_t*> lane_maps;   /* lane_map_for(): (cbx, groups, R, LS) -> device table */
     void* pin = nullptr;          /* pinned staging of csm_upload_grid */
     size_t pin_cap = 0;
     void* pin_scans = nullptr;    /* pinned staging of a batch's scans */
@@ -716,13 +717,110 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
     } while (0)
 #endif
 
+/* Which candidate (lane group g, column dxi) a thread of a pair kernel owns. A ds_read_b64
+ * serves a half-wave in one pass when its 32 slots cover the 64 banks once; slot (g, dxi) of an
+ * entry sits at bank pair (dxi + (R / 2) * LS * g) mod 32. With threads numbered through the
+ * groups in order (dxi = tid % cbx) every half-wave that holds the end of one group and the
+ * start of the next takes two passes (6 of 16 for cbx = 84: a quarter of the LDS cycles of a
+ * kernel the LDS read rate bounds). The table instead gives each group whole half-waves for its
+ * first 32 * floor(cbx / 32) columns and deals the remaining columns of all groups to the
+ * remaining half-waves so that a half-wave holds each bank pair once; what cannot be placed
+ * that way is collected in the last half-waves (cbx = 84, 6 groups, LS = 150: 17 passes per
+ * wave-round of reads instead of 21). Entry = idle << 15 | g << 8 | dxi; 0xffff = idle lane without
+ * a slot of its own. Returns null
+ * (threads in order) where the table would not save a pass. */
+int lane_map_for(csm_ctx* ctx, const PassPlan& pp, const uint16_t** out)
+{
+    *out = nullptr;
+    if (const char* e = getenv("CSM_LANE_MAP"))
+        if (atoi(e) == 0)
+            return CSM_OK;
+    const std::array<int, 4> key = { pp.cbx, pp.groups, pp.R, pp.lstride };
+    auto it = ctx->lane_maps.find(key);
+    if (it != ctx->lane_maps.end()) {
+        *out = it->second;
+        return CSM_OK;
+    }
+    uint16_t*& slot = ctx->lane_maps[key];
+    slot = nullptr;
+    const int nhw = kBlock / 32, nfull = pp.cbx / 32;
+    auto pos = [&](int g, int c) { return (c + (pp.R / 2) * pp.lstride * g) % 32; };
+    auto passes_of = [&](const std::vector<uint16_t>& t) {
+        int total = 0;
+        for (int h = 0; h < nhw; ++h) {
+            int cnt[32] = { 0 }, worst = 0;
+            for (int l = 0; l < 32; ++l)
+                if (t[h * 32 + l] != 0xffff)
+                    worst = std::max(worst, ++cnt[pos((t[h * 32 + l] >> 8) & 127, t[h * 32 + l] & 255)]);
+            total += worst;
+        }
+        return total;
+    };
+    std::vector<uint16_t> linear(kBlock, 0xffff), table(kBlock, 0xffff);
+    for (int tid = 0; tid < kBlock; ++tid)
+        if (tid / pp.cbx < pp.groups)
+            linear[tid] = (uint16_t)((tid / pp.cbx) << 8 | (tid % pp.cbx));
+    if (pp.cbx > 255 || pp.groups > 127 || pp.groups * nfull >= nhw)
+        return CSM_OK;
+    int hw = 0;
+    for (int g = 0; g < pp.groups; ++g)
+        for (int k = 0; k < nfull; ++k, ++hw)
+            for (int l = 0; l < 32; ++l)
+                table[hw * 32 + l] = (uint16_t)(g << 8 | (32 * k + l));
+    const int nrem = nhw - hw;
+    std::vector<std::vector<uint16_t>> lists(nrem);
+    std::vector<uint16_t> extra;
+    int seen[32] = { 0 };
+    for (int g = 0; g < pp.groups; ++g)
+        for (int c = 32 * nfull; c < pp.cbx; ++c) {
+            const int i = seen[pos(g, c)]++;
+            const uint16_t v = (uint16_t)(g << 8 | c);
+            if (i < nrem && lists[i].size() < 32)
+                lists[i].push_back(v);
+            else
+                extra.push_back(v);
+        }
+    for (uint16_t v : extra) {
+        int h = nrem - 1;
+        while (h >= 0 && lists[h].size() >= 32)
+            --h;
+        if (h < 0)
+            return CSM_OK;
+        lists[h].push_back(v);
+    }
+    for (int h = 0; h < nrem; ++h) {
+        bool used[32] = { false };
+        for (size_t l = 0; l < lists[h].size(); ++l) {
+            table[(hw + h) * 32 + l] = lists[h][l];
+            used[pos(lists[h][l] >> 8, lists[h][l] & 255)] = true;
+        }
+        /* idle lanes read too (the instruction is the wave's): each gets a slot of its own on a
+         * bank pair the half-wave does not use (group 0, column q), marked idle by bit 15 */
+        int q = 0;
+        for (size_t l = lists[h].size(); l < 32; ++l) {
+            while (q < 32 && (used[q] || q >= pp.cbx))
+                ++q;
+            if (q < 32) {
+                table[(hw + h) * 32 + l] = (uint16_t)(0x8000 | q);
+                used[q] = true;
+            }
+        }
+    }
+    if (passes_of(table) >= passes_of(linear))
+        return CSM_OK;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot), kBlock * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMemcpy(slot, table.data(), kBlock * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *out = slot;
+    return CSM_OK;
+}
+
 #define CALL_PAIRS_SINGLE(LS, RR, WW)                                                  \
     do {                                                                               \
         int rc_ = set_lds(ctx, k_score_pairs<LS, RR, WW>, lds);                        \
         if (rc_)                                                                       \
             return rc_;                                                                \
         hipLaunchKernelGGL((k_score_pairs<LS, RR, WW>), theta_major ? dim3(grid.y, grid.x, 1) : grid, \
-                           dim3(kBlock), lds, ctx->stream, job, pp.cbx, pp.groups, theta_major); \
+                           dim3(kBlock), lds, ctx->stream, job, pp.cbx, pp.groups, theta_major, lane_map); \
     } while (0)
 
 #define CALL_PAIRS_BATCH(LS, RR, WW)                                                   \
@@ -733,13 +831,13 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
                 return rc_;                                                            \
             hipLaunchKernelGGL((k_score_pairs2_batch<LS, RR, WW>),                     \
                                dim3(grid.x, (grid.y + 1) / 2, grid.z), dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups);              \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map);    \
         } else {                                                                       \
             int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);              \
             if (rc_)                                                                   \
                 return rc_;                                                            \
             hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups);              \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map);    \
         }                                                                              \
     } while (0)
 
@@ -753,6 +851,9 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
         int theta_major = (n_slices == 1 && (long)pp.ncb() * n_theta >= 4096 && pp.ncb() <= 65535) ? 1 : 0;
         if (const char* e = getenv("CSM_THETA_MAJOR"))
             theta_major = (atoi(e) != 0 && n_slices == 1 && pp.ncb() <= 65535) ? 1 : 0;
+        const uint16_t* lane_map = nullptr;
+        if (int rc = lane_map_for(ctx, pp, &lane_map))
+            return rc;
         PAIR_DISPATCH(CALL_PAIRS_SINGLE);
         if (!launched)
             return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
@@ -814,6 +915,9 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
             return fail(ctx, CSM_EINVAL, "internal: pair kernel batches are not tile-split");
         const size_t lds = pass_lds_bytes(pp);
         bool launched = false;
+        const uint16_t* lane_map = nullptr;
+        if (int rc = lane_map_for(ctx, pp, &lane_map))
+            return rc;
         PAIR_DISPATCH(CALL_PAIRS_BATCH);
         if (!launched)
             return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
@@ -1454,6 +1558,9 @@ int csm_destroy(csm_ctx* ctx)
             (void)hipFree(b->p);
     if (ctx->lut_dev)
         (void)hipFree(ctx->lut_dev);
+    for (auto& kv : ctx->lane_maps)
+        if (kv.second)
+            (void)hipFree(kv.second);
     if (ctx->pin)
         (void)hipHostFree(ctx->pin);
     if (ctx->pin_scans)

@@ -1138,6 +1138,12 @@ __device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t*
     auto issue = [&](uint32_t pbv, auto cls, unsigned long long (&q)[R / 2 + 1]) {
         constexpr int CLS = decltype(cls)::value;
         const uint32_t addr = lane_addr + (pbv & 0x7ffffu);
+#ifdef CSM_ABL_NOREADS
+        q[0] = q[1] = q[R / 2] = addr;
+        if (R >= 6) q[2] = addr;
+        if (R >= 8) q[3] = addr;
+        return;
+#endif
         lds_read_b64<0 * kRowBytes>(addr, q[0]);
         lds_read_b64<1 * kRowBytes>(addr, q[1]);
         if (R >= 6)
@@ -1156,6 +1162,11 @@ __device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t*
             v[2 * i + 1] = (uint32_t)(q[i] >> 32);
         }
         const uint32_t me = (pbv >> 24) & 15u, mo = pbv >> 28;
+#ifdef CSM_ABL_NOMADS
+        acc[0] += v[0] + v[2] + v[4] + v[R] + me + mo;
+        if (R >= 6) acc[1] += v[6];
+        return;
+#endif
         if (WEIGHTED) {
             /* the two multiply-adds of one accumulator are kept R instructions
              * apart: back to back the compiler pads them with s_nop */
@@ -1256,7 +1267,7 @@ __device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t*
  * Entries arrive sorted by class, TileRec.pad = class counts. */
 template <int LS, int R, bool WEIGHTED>
 __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, int groups, int slice,
-                                                 int n_slices, int t, int cb, int ncb)
+                                                 int n_slices, int t, int cb, int ncb, const uint16_t* lane_map)
 {
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
@@ -1270,8 +1281,17 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
         return;
     const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
 
-    const int dxi = tid % cbx, g = tid / cbx;
-    const bool lane_on = g < groups;
+    /* which candidate column and lane group this thread owns: in thread order, or by the
+     * host's table that keeps half-waves free of bank conflicts (lane_map_for, csm_api.hip) */
+    int dxi = tid % cbx, g = tid / cbx;
+    bool idle = false;
+    if (lane_map) {
+        const uint32_t m = lane_map[tid];
+        dxi = (int)(m & 255u);
+        g = (int)((m >> 8) & 127u);
+        idle = (m >> 15) != 0;
+    }
+    const bool lane_on = !idle && g < groups;
     const int x0 = job.x_lo + bx * cbx;
     const int y0 = job.y_lo + by * cby;
     constexpr int kRowBytes = LS * 8;                   /* one pair row of the region */
@@ -1279,7 +1299,8 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb = sm_cells + max_pieces * 256;
-    const int tb = lane_on ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
+    /* idle lanes of the table read the slot it gives them (a bank pair of their own) */
+    const int tb = lane_on || (idle && g < groups && dxi < cbx) ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     /* a wave none of whose lanes owns a candidate inside the window (the last row block
@@ -1375,7 +1396,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
  * are paid once per two slices (they were 29 % + 6 % of the single-slice kernel). */
 
 template <int LS, int R, bool WEIGHTED>
-__device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups)
+__device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map)
 {
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
@@ -1394,8 +1415,17 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
         return;
     const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
 
-    const int dxi = tid % cbx, g = tid / cbx;
-    const bool lane_on = g < groups;
+    /* which candidate column and lane group this thread owns: in thread order, or by the
+     * host's table that keeps half-waves free of bank conflicts (lane_map_for, csm_api.hip) */
+    int dxi = tid % cbx, g = tid / cbx;
+    bool idle = false;
+    if (lane_map) {
+        const uint32_t m = lane_map[tid];
+        dxi = (int)(m & 255u);
+        g = (int)((m >> 8) & 127u);
+        idle = (m >> 15) != 0;
+    }
+    const bool lane_on = !idle && g < groups;
     const int x0 = job.x_lo + bx * cbx;
     const int y0 = job.y_lo + by * cby;
     constexpr int kRowBytes = LS * 8;
@@ -1404,7 +1434,8 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb0 = sm_cells + max_pieces * 256;
     uint32_t* lpb1 = lpb0 + kPbMax;
-    const int tb = lane_on ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
+    /* idle lanes of the table read the slot it gives them (a bank pair of their own) */
+    const int tb = lane_on || (idle && g < groups && dxi < cbx) ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;      /* bytes */
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     /* see score_body_pairs: waves without a candidate inside the window do not gather */
@@ -1525,28 +1556,32 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
  * windows of the map -- for maps far larger than an L2 (configs[4]: 56 MB) that turns
  * the window copies from fabric traffic into L2 hits. */
 template <int LS, int R, bool WEIGHTED>
-__global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups, int theta_major)
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups, int theta_major,
+                                                           const uint16_t* lane_map)
 {
     if (theta_major)
-        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y,
+                                          lane_map);
     else
         score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, (int)blockIdx.y,
-                                          (int)blockIdx.x, (int)gridDim.x);
+                                          (int)blockIdx.x, (int)gridDim.x, lane_map);
 }
 
 /* grid = (candidate blocks, theta slices, jobs) */
 template <int LS, int R, bool WEIGHTED>
-__global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups)
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups,
+                                                                 const uint16_t* lane_map)
 {
     score_body_pairs<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, 0, 1, (int)blockIdx.y, (int)blockIdx.x,
-                                      (int)gridDim.x);
+                                      (int)gridDim.x, lane_map);
 }
 
 /* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
 template <int LS, int R, bool WEIGHTED>
-__global__ __launch_bounds__(kBlock, 4) void k_score_pairs2_batch(const ScoreJob* jobs, int cbx, int groups)
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs2_batch(const ScoreJob* jobs, int cbx, int groups,
+                                                                  const uint16_t* lane_map)
 {
-    score_body_pairs2<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups);
+    score_body_pairs2<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, lane_map);
 }
 
 /* ------------------------------------------------------------------ K2 */
