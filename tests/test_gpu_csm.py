@@ -110,3 +110,23 @@ def test_saturated_grid_never_overflows_the_packed_accumulators(gpu_ctx, oracle,
     assert np.array_equal(K, oK) and np.array_equal(S, oS)
     assert int(K.max()) == n_beams and int(S.max()) == 65535 * n_beams
     gpu_ctx.release_grid(3)
+
+
+def test_lane_table_on_and_off_give_identical_sums(gpu_ctx, oracle, monkeypatch):
+    """The pair kernels take the thread -> (lane group, column) assignment from a host
+    table that keeps half-waves free of LDS bank conflicts (lane_map_for, csm_api.hip);
+    CSM_LANE_MAP=0 numbers the threads through the groups in order. Both must give every
+    candidate's sums (84 x 84 window: 6 groups of 84 columns, the shape the table is for)."""
+    case = synth.csm_case(21, n_beams=1080, fov=1.5 * math.pi)
+    rx, ry, rt, L = 2.0, 2.0, math.radians(4), 4
+    (wx, wy, wt), col, row, mk = _window_for(case, rx, ry, rt, L)
+    gpu_ctx.upload_grid(4, case["grid"])
+    gpu_ctx.build_pyramid(4, [1, L])
+    w = gpu_ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, L, 1, mk, 0.0)
+    want, oS, oK, oCK = oracle.csm_closed_form(case, rx, ry, rt, L, dump=True)
+    for setting in ("1", "0"):
+        monkeypatch.setenv("CSM_LANE_MAP", setting)
+        res, S, K, CK = gpu_ctx.score_window(4, w, col, row, dump=True)
+        assert np.array_equal(S, oS) and np.array_equal(K, oK), setting
+        assert (res["best_x"], res["best_y"], res["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"])
+    gpu_ctx.release_grid(4)
