@@ -831,13 +831,13 @@ int lane_map_for(csm_ctx* ctx, const PassPlan& pp, const uint16_t** out)
                 return rc_;                                                            \
             hipLaunchKernelGGL((k_score_pairs2_batch<LS, RR, WW>),                     \
                                dim3(grid.x, (grid.y + 1) / 2, grid.z), dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map);    \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map); \
         } else {                                                                       \
             int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);              \
             if (rc_)                                                                   \
                 return rc_;                                                            \
             hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map);    \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map); \
         }                                                                              \
     } while (0)
 
@@ -918,6 +918,10 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
         const uint16_t* lane_map = nullptr;
         if (int rc = lane_map_for(ctx, pp, &lane_map))
             return rc;
+        /* one job's workgroups on one XCD (k_score_pairs*_batch, xcd_block); CSM_XCD_MAP=0: identity */
+        int xcd_map = 1;
+        if (const char* e = getenv("CSM_XCD_MAP"))
+            xcd_map = atoi(e) != 0;
         PAIR_DISPATCH(CALL_PAIRS_BATCH);
         if (!launched)
             return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);

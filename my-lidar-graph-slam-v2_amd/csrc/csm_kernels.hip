@@ -1396,11 +1396,12 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
  * are paid once per two slices (they were 29 % + 6 % of the single-slice kernel). */
 
 template <int LS, int R, bool WEIGHTED>
-__device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map)
-{
+__device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map,
+                                                  int bid_x, int bid_y, int grid_x)
+{   /* bid_x: candidate block, bid_y: pair of theta slices (the kernel's, after its XCD mapping) */
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
-    const int t0 = 2 * (int)blockIdx.y, t1 = t0 + 1;
+    const int t0 = 2 * bid_y, t1 = t0 + 1;
     /* values loaded from the job are uniform, but only readfirstlane tells the compiler:
      * everything derived from them then stays in scalar registers and scalar branches */
     const int n_theta = __builtin_amdgcn_readfirstlane(job.n_theta);
@@ -1409,7 +1410,7 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     const bool two = t1 < n_theta;
     const int tid = threadIdx.x;
     const int ncbx = (job.nx + cbx - 1) / cbx;
-    const int bx = blockIdx.x % ncbx, by = blockIdx.x / ncbx;
+    const int bx = bid_x % ncbx, by = bid_x / ncbx;
     const int cby = groups * R;
     if (by * cby >= job.ny)
         return;
@@ -1543,10 +1544,10 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     }
     pairs_finish<R>(acc0, S0, K0);
     pairs_finish<R>(acc1, S1, K1);
-    score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags, (int)blockIdx.x, (int)gridDim.x);
+    score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags, bid_x, grid_x);
     if (two) {
         __syncthreads();                                 /* the epilogue's reduction arrays */
-        score_epilogue<R>(job, S1, K1, t1, bx, by, cbx, cby, g, dxi, lane_on, qflags, (int)blockIdx.x, (int)gridDim.x);
+        score_epilogue<R>(job, S1, K1, t1, bx, by, cbx, cby, g, dxi, lane_on, qflags, bid_x, grid_x);
     }
 }
 
@@ -1567,21 +1568,50 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx
                                           (int)blockIdx.x, (int)gridDim.x, lane_map);
 }
 
+/* Which (candidate block, slice, job) a workgroup of a batch launch works on. Workgroups are
+ * handed to the 8 XCDs round-robin in the order of their linear id, and every XCD has an L2 of
+ * its own: with the identity mapping the ~100 workgroups of one job -- which copy windows of
+ * ONE map -- are spread over all eight L2s, and each of them fetches that map's windows from
+ * the fabric. With xcd_map the jobs are dealt to the XCDs instead (job j on XCD j mod 8): linear
+ * id L -> XCD L mod 8, the XCD's q-th workgroup (q = L / 8) -> job 8 (q / P) + L mod 8, part
+ * q mod P of it (P = workgroups per job). Jobs beyond the last multiple of 8 keep the identity
+ * mapping. (BASELINE configs[2], [3]: one map per job; configs[1]'s windows share one map.) */
+__device__ __forceinline__ void xcd_block(int xcd_map, int& bx, int& by, int& bz)
+{
+    bx = (int)blockIdx.x;
+    by = (int)blockIdx.y;
+    bz = (int)blockIdx.z;
+    if (!xcd_map)
+        return;
+    const uint32_t per_job = gridDim.x * gridDim.y;
+    const uint32_t jobs8 = gridDim.z & ~7u;
+    const uint32_t lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (lin >= per_job * jobs8)
+        return;
+    const uint32_t q = lin >> 3, slot = q / per_job, part = q - slot * per_job;
+    bz = (int)(8u * slot + (lin & 7u));
+    by = (int)(part / gridDim.x);
+    bx = (int)(part - (uint32_t)by * gridDim.x);
+}
+
 /* grid = (candidate blocks, theta slices, jobs) */
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups,
-                                                                 const uint16_t* lane_map)
+                                                                 const uint16_t* lane_map, int xcd_map)
 {
-    score_body_pairs<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, 0, 1, (int)blockIdx.y, (int)blockIdx.x,
-                                      (int)gridDim.x, lane_map);
+    int bx, by, bz;
+    xcd_block(xcd_map, bx, by, bz);
+    score_body_pairs<LS, R, WEIGHTED>(jobs[bz], cbx, groups, 0, 1, by, bx, (int)gridDim.x, lane_map);
 }
 
 /* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs2_batch(const ScoreJob* jobs, int cbx, int groups,
-                                                                  const uint16_t* lane_map)
+                                                                  const uint16_t* lane_map, int xcd_map)
 {
-    score_body_pairs2<LS, R, WEIGHTED>(jobs[blockIdx.z], cbx, groups, lane_map);
+    int bx, by, bz;
+    xcd_block(xcd_map, bx, by, bz);
+    score_body_pairs2<LS, R, WEIGHTED>(jobs[bz], cbx, groups, lane_map, bx, by, (int)gridDim.x);
 }
 
 /* ------------------------------------------------------------------ K2 */
