@@ -206,11 +206,16 @@ def make_loop_queries(ctx, lo, hi):
     return queries, t_up
 
 
-def loop_roofline(leaves, fine_ms, fine_n, entries_per_leaf_query=None):
+def loop_roofline(leaves, fine_ms, fine_n, entries_per_leaf_query=None, n_queries=None):
     alg = 2.0 * N_BEAMS * leaves
     avg = fine_ms / max(1, fine_n) * 1e-3
+    # HBM bytes per leaf launch: the committed PMC passes of the 256-query batch (one map per query)
+    traffic, traffic_src = pmc_traffic(os.path.join(ROOT, "profiles", "r02_loop_pmc_traffic.json"))
+    if traffic is not None and n_queries not in (None, 256):
+        traffic, traffic_src = traffic * n_queries / 256.0, traffic_src + "; scaled to %d queries" % n_queries
     d = {"bound": "lds", "kernel": "k_score_pairs_batch (leaf level, all queries of the batch in one launch)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
-         "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": None,
+         "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": traffic, "traffic_source": traffic_src,
+         "hbm_frac_measured": traffic / avg / 1e9 / HBM_PEAK_GBS if traffic is not None and avg > 0 else None,
          "logical_hbm_gbs": alg / avg / 1e9 if avg > 0 else 0.0,
          "logical_hbm_frac": alg / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0}
     if entries_per_leaf_query is not None and avg > 0:
@@ -311,7 +316,7 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
         leaves = leaves_local
         found = sum(o["pose_found"] for o in outs)
     if rank == 0:
-        rl = loop_roofline(leaves_local, fine_ms, fine_n, loop_gathers(queries, LOOP_PARAMS))
+        rl = loop_roofline(leaves_local, fine_ms, fine_n, loop_gathers(queries, LOOP_PARAMS), len(queries))
         print(json.dumps({
             "metric": METRIC, "value": leaves * args.steps / dt, "unit": "candidate poses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -373,7 +378,7 @@ def measure_loop_config(dev_index, n_sub, steps=5):
     leaves = outs.total("candidates")
     found = sum(1 for o in outs if o["pose_found"])
     flagged = sum(1 for o in outs if o["raw"]["flags"])
-    rl = loop_roofline(leaves, fine_ms, fine_n, loop_gathers(queries, LOOP_PARAMS))
+    rl = loop_roofline(leaves, fine_ms, fine_n, loop_gathers(queries, LOOP_PARAMS), len(queries))
     ctx.close()
     return {"workload": "configs[%d]%s: one 1080-beam query scan per 256 of %d candidate submaps (one room family, own clutter / map offset / initial pose per submap), 3-level grids, 2.5 m x 2.5 m x "
                         "0.5 rad, thresholds 0.55/0.6" % (2 if n_sub == 256 else 3,

@@ -35,6 +35,8 @@ run_pmc cfg5 WRITE_SIZE --steps 1 --warmup 1 --no-cpu-baseline || exit 1
 unset CSM_BENCH_SCANS CSM_BENCH_DISTINCT CSM_BENCH_CONFIGS CSM_BENCH_WINDOWS
 # configs[2]: the branch-and-bound batch
 run_stats loop --workload loop --steps 10 --no-cpu-baseline || exit 1
+run_pmc loop FETCH_SIZE --workload loop --steps 3 --warmup 1 --no-cpu-baseline || exit 1
+run_pmc loop WRITE_SIZE --workload loop --steps 3 --warmup 1 --no-cpu-baseline || exit 1
 
 python3 - "$TAG" <<'PY'
 import csv, glob, json, os, sys
@@ -51,7 +53,8 @@ def counters(name):
                 d = acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], [0.0, 0])
                 d[0] += float(row["Counter_Value"]); d[1] += 1
     return {k: {c: {"mean_KB": s / n, "dispatches": n} for c, (s, n) in v.items()} for k, v in acc.items()}
-for name, pick, wpl in (("csm", "_batch<", int(os.environ.get("CSM_BENCH_WINDOWS", "256"))), ("cfg5", "k_score_pairs<", 1)):
+for name, pick, wpl in (("csm", "_batch<", int(os.environ.get("CSM_BENCH_WINDOWS", "256"))), ("cfg5", "k_score_pairs<", 1),
+                        ("loop", "_batch<", 256)):
     per = counters(name)
     dom = [k for k in per if pick in k and "k_score_pairs" in k]
     if name == "cfg5":      # the 2000x2000 query's kernel: the single-window pair kernel with the widest rows
