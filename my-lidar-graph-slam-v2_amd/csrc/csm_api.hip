@@ -851,6 +851,8 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
         int theta_major = (n_slices == 1 && (long)pp.ncb() * n_theta >= 4096 && pp.ncb() <= 65535) ? 1 : 0;
         if (const char* e = getenv("CSM_THETA_MAJOR"))
             theta_major = (atoi(e) != 0 && n_slices == 1 && pp.ncb() <= 65535) ? 1 : 0;
+        if (theta_major && !(getenv("CSM_XCD_MAP") && atoi(getenv("CSM_XCD_MAP")) == 0))
+            theta_major |= 2;        /* candidate blocks dealt to the XCDs (k_score_pairs) */
         const uint16_t* lane_map = nullptr;
         if (int rc = lane_map_for(ctx, pp, &lane_map))
             return rc;

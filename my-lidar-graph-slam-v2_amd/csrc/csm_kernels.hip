@@ -1560,10 +1560,21 @@ template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx, int groups, int theta_major,
                                                            const uint16_t* lane_map)
 {
-    if (theta_major)
-        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y,
-                                          lane_map);
-    else
+    if (theta_major) {
+        /* theta_major & 2: candidate blocks dealt to the XCDs (block b on XCD b mod 8), so that the
+         * windows of a block -- nearly the same for neighbouring slices -- are fetched into one L2
+         * instead of all eight: linear id L -> XCD L mod 8, its q-th workgroup (q = L / 8) ->
+         * block 8 (q / T) + L mod 8, slice q mod T (T slices); blocks beyond the last multiple of
+         * 8 keep the identity order */
+        uint32_t t = blockIdx.x, cb = blockIdx.y;
+        const uint32_t n_t = gridDim.x, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((theta_major & 2) && lin < n_t * (gridDim.y & ~7u)) {
+            const uint32_t q = lin >> 3, slot = q / n_t;
+            t = q - slot * n_t;
+            cb = 8u * slot + (lin & 7u);
+        }
+        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)t, (int)cb, (int)gridDim.y, lane_map);
+    } else
         score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, (int)blockIdx.y,
                                           (int)blockIdx.x, (int)gridDim.x, lane_map);
 }
