@@ -831,13 +831,13 @@ int lane_map_for(csm_ctx* ctx, const PassPlan& pp, const uint16_t** out)
                 return rc_;                                                            \
             hipLaunchKernelGGL((k_score_pairs2_batch<LS, RR, WW>),                     \
                                dim3(grid.x, (grid.y + 1) / 2, grid.z), dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map); \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map, bb); \
         } else {                                                                       \
             int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);              \
             if (rc_)                                                                   \
                 return rc_;                                                            \
             hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map); \
+                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map, bb); \
         }                                                                              \
     } while (0)
 
@@ -906,6 +906,25 @@ int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n
     return CSM_OK;
 }
 
+/* One launch of the pair kernels over row blocks [first block of `pp`'s numbering ...) of a batch. */
+int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& pp, dim3 grid, BlockBase bb)
+{
+    const size_t lds = pass_lds_bytes(pp);
+    bool launched = false;
+    const uint16_t* lane_map = nullptr;
+    if (int rc = lane_map_for(ctx, pp, &lane_map))
+        return rc;
+    /* one job's workgroups on one XCD (k_score_pairs*_batch, xcd_block); CSM_XCD_MAP=0: identity */
+    int xcd_map = 1;
+    if (const char* e = getenv("CSM_XCD_MAP"))
+        xcd_map = atoi(e) != 0;
+    PAIR_DISPATCH(CALL_PAIRS_BATCH);
+    if (!launched)
+        return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d R %d", pp.lstride, pp.R);
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
 int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const PassPlan& pp,
                        int n_theta_max, int n_slices, int theta_groups = 0)
 {
@@ -915,20 +934,23 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
     if (pp.pairs) {
         if (n_slices != 1)
             return fail(ctx, CSM_EINVAL, "internal: pair kernel batches are not tile-split");
-        const size_t lds = pass_lds_bytes(pp);
-        bool launched = false;
-        const uint16_t* lane_map = nullptr;
-        if (int rc = lane_map_for(ctx, pp, &lane_map))
+        /* The last row block of a window rarely needs all R = 8 rows of its lanes (84 rows in
+         * blocks of 48: the second block has 36). Where R = 6 covers it with the same lane
+         * groups, that block is a launch of its own: three quarters of the reads and
+         * multiply-adds per entry for half of the workgroups (CSM_PAIR_TAIL=0: one launch). */
+        const int cby = pp.groups * pp.R, tail_rows = pp.ny - (pp.ncby - 1) * cby;
+        const bool split = pp.R == 8 && pp.ncby >= 2 && tail_rows > 0 && tail_rows <= pp.groups * 6 &&
+                           !(getenv("CSM_PAIR_TAIL") && atoi(getenv("CSM_PAIR_TAIL")) == 0);
+        if (!split)
+            return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() });
+        PassPlan tail = pp;
+        tail.R = 6;
+        int rc = launch_pairs_batch(ctx, jobs_dev, pp, dim3(pp.ncbx * (pp.ncby - 1), grid.y, grid.z),
+                                    BlockBase{ 0, 0, pp.ncb() });
+        if (rc)
             return rc;
-        /* one job's workgroups on one XCD (k_score_pairs*_batch, xcd_block); CSM_XCD_MAP=0: identity */
-        int xcd_map = 1;
-        if (const char* e = getenv("CSM_XCD_MAP"))
-            xcd_map = atoi(e) != 0;
-        PAIR_DISPATCH(CALL_PAIRS_BATCH);
-        if (!launched)
-            return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
-        HIP_TRY(ctx, hipGetLastError());
-        return CSM_OK;
+        return launch_pairs_batch(ctx, jobs_dev, tail, dim3(pp.ncbx, grid.y, grid.z),
+                                  BlockBase{ (pp.ncby - 1) * cby, pp.ncbx * (pp.ncby - 1), pp.ncb() });
     }
     const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
     size_t lds = pass_lds_bytes(pp);

@@ -1071,6 +1071,15 @@ __global__ __launch_bounds__(256) void k_expand_pairs(const uint16_t* __restrict
     }
 }
 
+/* Where a pair-kernel launch sits among the candidate blocks of its window: a window's last
+ * row block may be a launch of its own with fewer rows per lane (R = 6 for 36 rows instead of
+ * R = 8 with a quarter of the lanes' rows outside the window: launch_score_batch). */
+struct BlockBase {
+    int row_base;       /* first candidate row of this launch's row block 0 */
+    int cb_base;        /* this launch's block 0 in the window's numbering (BlockBest slots) */
+    int ncb;            /* candidate blocks of the window, all launches */
+};
+
 /* Inclusive prefix sum over the wave's 64 lanes, data-parallel primitives only (no LDS
  * traffic: the gather counts its own LDS reads in lgkmcnt). */
 __device__ __forceinline__ int wave_prefix_sum(int x)
@@ -1267,7 +1276,8 @@ __device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t*
  * Entries arrive sorted by class, TileRec.pad = class counts. */
 template <int LS, int R, bool WEIGHTED>
 __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, int groups, int slice,
-                                                 int n_slices, int t, int cb, int ncb, const uint16_t* lane_map)
+                                                 int n_slices, int t, int cb, const uint16_t* lane_map,
+                                                 BlockBase bb)
 {
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
@@ -1277,7 +1287,8 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     const int ncbx = (job.nx + cbx - 1) / cbx;
     const int bx = cb % ncbx, by = cb / ncbx;
     const int cby = groups * R;
-    if (by * cby >= job.ny)
+    const int row0 = bb.row_base + by * cby;         /* first candidate row of this workgroup */
+    if (row0 >= job.ny)
         return;
     const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
 
@@ -1293,7 +1304,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
     }
     const bool lane_on = !idle && g < groups;
     const int x0 = job.x_lo + bx * cbx;
-    const int y0 = job.y_lo + by * cby;
+    const int y0 = job.y_lo + row0;
     constexpr int kRowBytes = LS * 8;                   /* one pair row of the region */
     const int prows_full = (kTile + cby) / 2 + 1;
     const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
@@ -1307,7 +1318,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
      * of 84 rows in blocks of 48: rows 88..95) copies windows and keeps the barriers,
      * but gathers nothing */
     const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
-                                                       by * cby + g * R < job.ny) != 0;
+                                                       row0 + g * R < job.ny) != 0;
 
     uint32_t S[R], K[R], acc[R];
 #pragma unroll
@@ -1383,7 +1394,8 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
             pairs_gather<LS, R, WEIGHTED>(lane_addr, lpb, lane, cnt, end_both, end_even, acc, S, K, fs);
     }
     pairs_finish<R>(acc, S, K);
-    score_epilogue<R>(job, S, K, t, bx, by, cbx, cby, g, dxi, lane_on, qflags, cb, ncb);
+    /* the epilogue wants the row block as (by, cby) and uses only their product */
+    score_epilogue<R>(job, S, K, t, bx, 1, cbx, row0, g, dxi, lane_on, qflags, cb + bb.cb_base, bb.ncb);
 }
 
 /* ---- two theta slices per workgroup ---------------------------------------
@@ -1397,7 +1409,7 @@ __device__ __forceinline__ void score_body_pairs(const ScoreJob& job, int cbx, i
 
 template <int LS, int R, bool WEIGHTED>
 __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map,
-                                                  int bid_x, int bid_y, int grid_x)
+                                                  int bid_x, int bid_y, BlockBase bb)
 {   /* bid_x: candidate block, bid_y: pair of theta slices (the kernel's, after its XCD mapping) */
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
@@ -1412,7 +1424,8 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     const int ncbx = (job.nx + cbx - 1) / cbx;
     const int bx = bid_x % ncbx, by = bid_x / ncbx;
     const int cby = groups * R;
-    if (by * cby >= job.ny)
+    const int row0 = bb.row_base + by * cby;         /* first candidate row of this workgroup */
+    if (row0 >= job.ny)
         return;
     const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
 
@@ -1428,7 +1441,7 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     }
     const bool lane_on = !idle && g < groups;
     const int x0 = job.x_lo + bx * cbx;
-    const int y0 = job.y_lo + by * cby;
+    const int y0 = job.y_lo + row0;
     constexpr int kRowBytes = LS * 8;
     const int prows_full = (kTile + cby) / 2 + 1;
     const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
@@ -1441,7 +1454,7 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     /* see score_body_pairs: waves without a candidate inside the window do not gather */
     const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
-                                                       by * cby + g * R < job.ny) != 0;
+                                                       row0 + g * R < job.ny) != 0;
 
     uint32_t S0[R], K0[R], acc0[R], S1[R], K1[R], acc1[R];
 #pragma unroll
@@ -1544,10 +1557,10 @@ __device__ __forceinline__ void score_body_pairs2(const ScoreJob& job, int cbx, 
     }
     pairs_finish<R>(acc0, S0, K0);
     pairs_finish<R>(acc1, S1, K1);
-    score_epilogue<R>(job, S0, K0, t0, bx, by, cbx, cby, g, dxi, lane_on, qflags, bid_x, grid_x);
+    score_epilogue<R>(job, S0, K0, t0, bx, 1, cbx, row0, g, dxi, lane_on, qflags, bid_x + bb.cb_base, bb.ncb);
     if (two) {
         __syncthreads();                                 /* the epilogue's reduction arrays */
-        score_epilogue<R>(job, S1, K1, t1, bx, by, cbx, cby, g, dxi, lane_on, qflags, bid_x, grid_x);
+        score_epilogue<R>(job, S1, K1, t1, bx, 1, cbx, row0, g, dxi, lane_on, qflags, bid_x + bb.cb_base, bb.ncb);
     }
 }
 
@@ -1573,10 +1586,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx
             t = q - slot * n_t;
             cb = 8u * slot + (lin & 7u);
         }
-        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)t, (int)cb, (int)gridDim.y, lane_map);
+        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)t, (int)cb, lane_map,
+                                          BlockBase{ 0, 0, (int)gridDim.y });
     } else
         score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, blockIdx.z, gridDim.z, (int)blockIdx.y,
-                                          (int)blockIdx.x, (int)gridDim.x, lane_map);
+                                          (int)blockIdx.x, lane_map, BlockBase{ 0, 0, (int)gridDim.x });
 }
 
 /* Which (candidate block, slice, job) a workgroup of a batch launch works on. Workgroups are
@@ -1608,21 +1622,21 @@ __device__ __forceinline__ void xcd_block(int xcd_map, int& bx, int& by, int& bz
 /* grid = (candidate blocks, theta slices, jobs) */
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups,
-                                                                 const uint16_t* lane_map, int xcd_map)
+                                                                 const uint16_t* lane_map, int xcd_map, BlockBase bb)
 {
     int bx, by, bz;
     xcd_block(xcd_map, bx, by, bz);
-    score_body_pairs<LS, R, WEIGHTED>(jobs[bz], cbx, groups, 0, 1, by, bx, (int)gridDim.x, lane_map);
+    score_body_pairs<LS, R, WEIGHTED>(jobs[bz], cbx, groups, 0, 1, by, bx, lane_map, bb);
 }
 
 /* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs2_batch(const ScoreJob* jobs, int cbx, int groups,
-                                                                  const uint16_t* lane_map, int xcd_map)
+                                                                  const uint16_t* lane_map, int xcd_map, BlockBase bb)
 {
     int bx, by, bz;
     xcd_block(xcd_map, bx, by, bz);
-    score_body_pairs2<LS, R, WEIGHTED>(jobs[bz], cbx, groups, lane_map, bx, by, (int)gridDim.x);
+    score_body_pairs2<LS, R, WEIGHTED>(jobs[bz], cbx, groups, lane_map, bx, by, bb);
 }
 
 /* ------------------------------------------------------------------ K2 */
