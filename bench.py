@@ -717,7 +717,7 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
             },
             "roofline": {
                 "bound": "lds",
-                "kernel": "k_score_pairs2_batch<150, 8> + <150, 6> (fine level of %d windows: the 48-row blocks, then the 36-row blocks; avg_launch_us spans both launches)" % WINDOWS_PER_LAUNCH,
+                "kernel": "k_score_pairs2_batch<150, 8> + <156, 6> (fine level of %d windows: the 48-row blocks, then the 36-row blocks; avg_launch_us spans both launches)" % WINDOWS_PER_LAUNCH,
                 "achieved": achieved,
                 "peak": LDS_PEAK_GBS,
                 "unit": "GB/s",

@@ -446,8 +446,9 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
  * the LDS region = alignment column + 64-cell tile + cbx - 1 candidates, even
  * (16-byte rows for the LDS-DMA pieces). Instantiated for these LS; a candidate
  * block may be any width cbx <= LS - 65 (124: the conflict-free pitch of R = 6, cbx = 52,
- * the branch-and-bound detector's default window). */
-const int kPairLS[] = { 86, 98, 118, 124, 130, 150, 162, 182 };
+ * the branch-and-bound detector's default window; 156: that of R = 6, cbx = 84, the 36-row
+ * tail block of the frontend window). */
+const int kPairLS[] = { 86, 98, 118, 124, 130, 150, 156, 162, 182 };
 
 size_t pair_lds_bytes(int ls, int cby, int lists)
 {
@@ -706,13 +707,13 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
 #ifdef CSM_FAST_BUILD
 #define PAIR_DISPATCH(CALL)                                                            \
     do {                                                                               \
-        PAIR_CASE(150, CALL)                                                           \
+        PAIR_CASE(150, CALL) PAIR_CASE(156, CALL)                                      \
     } while (0)
 #else
 #define PAIR_DISPATCH(CALL)                                                            \
     do {                                                                               \
         PAIR_CASE(86, CALL) PAIR_CASE(98, CALL) PAIR_CASE(118, CALL) PAIR_CASE(124, CALL) \
-        PAIR_CASE(130, CALL) PAIR_CASE(150, CALL) PAIR_CASE(162, CALL)                 \
+        PAIR_CASE(130, CALL) PAIR_CASE(150, CALL) PAIR_CASE(156, CALL) PAIR_CASE(162, CALL) \
         PAIR_CASE(182, CALL)                                                           \
     } while (0)
 #endif
@@ -945,6 +946,17 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
             return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() });
         PassPlan tail = pp;
         tail.R = 6;
+        /* its conflict-free row pitch, where one is instantiated close by (plan_pass_pairs' rule;
+         * CSM_PAIR_TAIL_LS forces a pitch for tuning) */
+        for (int ls : kPairLS)
+            if (ls >= pp.lstride && ls <= pp.lstride + 8 && ((tail.R / 2) * ls - tail.cbx) % 32 == 0 &&
+                pair_lds_bytes(ls, tail.groups * tail.R, tail.lists) <= 80 * 1024 - 1024) {
+                tail.lstride = ls;
+                break;
+            }
+        if (const char* e = getenv("CSM_PAIR_TAIL_LS"))
+            if (atoi(e) >= tail.cbx + 65 && atoi(e) % 2 == 0)
+                tail.lstride = atoi(e);
         int rc = launch_pairs_batch(ctx, jobs_dev, pp, dim3(pp.ncbx * (pp.ncby - 1), grid.y, grid.z),
                                     BlockBase{ 0, 0, pp.ncb() });
         if (rc)
