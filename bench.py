@@ -118,6 +118,36 @@ def pmc_traffic(path=None):
         return None, None
 
 
+def verify_sample(wl, rec_raw, scans_per_step, n_distinct, n_check):
+    """After the timed region: n_check records of the last step, spread over its
+    launch chains, against the CPU oracle's literal ScanMatcherCorrelative sweep
+    (the checker, never the thing measured). Raises on a mismatch; returns the
+    number of records compared."""
+    if n_check <= 0:
+        return 0
+    import numpy as np
+    from csm_hip import _lib as L
+    from oracle import oracle as O
+    rx, ry, rt, Lr = wl["params"]
+    coarse = O.boxmax(wl["grid"], Lr)
+    picks = sorted(set(int(i) for i in np.linspace(0, scans_per_step - 1, n_check)))
+    compared = 0
+    for j in picks:
+        sc = wl["scans"][j % n_distinct]
+        r = L.Result.from_buffer_copy(rec_raw[48 * j:48 * (j + 1)])
+        case = dict(grid=wl["grid"], geom=wl["geom"], angles=sc["angles"], ranges=sc["ranges"],
+                    rel_pose=sc["rel_pose"], init_pose=sc["init_pose"])
+        lit = O.csm(case, rx, ry, rt, Lr, coarse=coarse)
+        if r.flags & (L.FLAG_EDGE_BAND | L.FLAG_KEY_TIE):
+            continue            # to be finished by csm_resolve_window_dev: not final as it stands
+        got = (r.found, r.best_x, r.best_y, r.best_theta, r.score)
+        want = (lit["found"], lit["bestX"], lit["bestY"], lit["bestT"], lit["scoreMax"])
+        if got != want:
+            raise AssertionError("bench record %d differs from the oracle: %r != %r" % (j, got, want))
+        compared += 1
+    return compared
+
+
 def cpu_baseline(wl, budget_s=10.0, max_scans=2000):
     """The CPU oracle (literal ScanMatcherCorrelative sweep with pruning) on the
     first scans of the same workload: one core (the reference is
@@ -668,8 +698,10 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
         assert torch.equal(mine, results), "all-gather read the records before they were written"
 
     # sanity: every scan found a pose and the record decodes
-    rec = np.frombuffer(results.cpu().numpy().tobytes(), dtype=np.int32).reshape(scans_per_step, 12)
+    rec_raw = results.cpu().numpy().tobytes()
+    rec = np.frombuffer(rec_raw, dtype=np.int32).reshape(scans_per_step, 12)
     n_found = int(rec[:, 0].sum())
+    verified = verify_sample(wl, rec_raw, scans_per_step, n_distinct, args.verify) if rank == 0 else 0
 
     if rank == 0:
         total = cands_per_step * args.steps * world
@@ -714,6 +746,9 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
                 "parallelism": "independent replicas per GPU, all-gather of 48-B best records" if world > 1
                                else "single GPU",
                 "poses_found": n_found,
+                "verified": verified,
+                "verified_note": "records of the last timed step compared, after the timed region, with the CPU "
+                                 "oracle's literal sweep (best x, y, theta and the f64 score at tolerance 0)",
             },
             "roofline": {
                 "bound": "lds",
@@ -766,6 +801,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=24,
+                    help="records of the last timed step compared with the CPU oracle after the timed region "
+                         "(configs[1] workload; 0 = none)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the short side runs of configs[2], [3] at N = 1, [4] and the single-query latency")
     ap.add_argument("--workload", choices=["auto", "csm", "loop", "loop4", "map"], default="auto",

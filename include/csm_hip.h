@@ -59,9 +59,25 @@ extern "C" {
 
 typedef struct csm_ctx csm_ctx;
 
+/* csm_config.tuning_off: switches individual launch optimisations OFF (A/B
+ * measurements, parity tests of both forms). 0 = the defaults. The library never
+ * reads the environment on a launch path; forced launch shapes exist only in
+ * tuning builds (-DCSM_TUNING), read once in csm_create. */
+#define CSM_TUNE_NO_LANE_MAP         1u   /* threads numbered through the lane groups in order */
+#define CSM_TUNE_NO_XCD_MAP          2u   /* identity workgroup -> XCD order in batch launches */
+#define CSM_TUNE_NO_PAIR_TAIL        4u   /* a window's last row block stays in the R = 8 launch */
+#define CSM_TUNE_NO_TWO_SLICES       8u   /* batch fine kernel: one theta slice per workgroup */
+#define CSM_TUNE_NO_THETA_MAJOR     16u   /* large single-window launches stay block-major */
+#define CSM_TUNE_NO_TILE_SPLIT      32u   /* small single windows are never tile-split */
+#define CSM_TUNE_MAP_HOST_PROJECTION 64u  /* map building: hit points computed on the host */
+#define CSM_TUNE_NO_JOINT          128u   /* batch fine kernel: per-slice entry lists (round-2 form) */
+
 typedef struct {
-    int32_t device_id;      /* HIP device ordinal */
-    int32_t reserved[7];
+    int32_t  device_id;          /* HIP device ordinal */
+    uint32_t tuning_off;         /* CSM_TUNE_* bits */
+    int32_t  map_uncertain_cap;  /* > 0: capacity of the map builder's list of uncertified
+                                    beams (tests of its overflow path); 0 = default */
+    int32_t  reserved[5];
 } csm_config;
 
 /* Geometry of a grid map: inc/grid_map_new/grid_map_geometry.hpp:228-240 */
@@ -263,6 +279,14 @@ int  csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
 int  csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids,
                            const csm_window* windows, const int32_t* const* hit_col_dev,
                            const int32_t* const* hit_row_dev, csm_result* out_dev);
+/* The same launch chain with a dump of every candidate's integer sums for parity
+ * tests of the batched kernels: dump_s_dev[i] / dump_k_dev[i] are device pointers
+ * (or NULL, per window or for the whole array) to S [n_theta][nx][ny] uint32 and
+ * K [..] uint16 of window i (nx = ceil((2*win_x+1)/L)*L). */
+int  csm_score_windows_dump_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids,
+                                const csm_window* windows, const int32_t* const* hit_col_dev,
+                                const int32_t* const* hit_row_dev, csm_result* out_dev,
+                                uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev);
 /* Synchronises, reads *out_dev and, when it carries a key tie or an edge-band
  * flag, runs the exact device paths (f64 tie replay / literal sequential
  * sweep) for the window just scored with csm_score_window_dev(); no-op
@@ -403,6 +427,12 @@ void csm_shard_bounds(int32_t n_queries, int32_t member, int32_t n_members,
  * device twice gives two members on it (two streams): meant for tests on a
  * one-GPU box. */
 int  csm_group_create(const int32_t* device_ids, int32_t n_devices, csm_group** out);
+/* The same with the members' configuration (member_cfg->device_id is ignored; NULL =
+ * defaults) and CSM_GROUP_* flags. */
+#define CSM_GROUP_FORCE_RCCL 1u  /* take the RCCL exchange also for a single member (a one-rank
+                                    communicator: the call sequence on a one-GPU box) */
+int  csm_group_create_ex(const int32_t* device_ids, int32_t n_devices, const csm_config* member_cfg,
+                         uint32_t flags, csm_group** out);
 int  csm_group_destroy(csm_group* group);
 int32_t csm_group_size(const csm_group* group);
 /* The member's context: upload / release the maps of the queries its block will

@@ -29,7 +29,14 @@ FLAG_PROJ_DELTA = 16
 
 
 class Config(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("device_id", C.c_int32), ("tuning_off", C.c_uint32), ("map_uncertain_cap", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+# csm_config.tuning_off bits (include/csm_hip.h)
+TUNE_NO_LANE_MAP, TUNE_NO_XCD_MAP, TUNE_NO_PAIR_TAIL, TUNE_NO_TWO_SLICES = 1, 2, 4, 8
+TUNE_NO_THETA_MAJOR, TUNE_NO_TILE_SPLIT, TUNE_MAP_HOST_PROJECTION, TUNE_NO_JOINT = 16, 32, 64, 128
+GROUP_FORCE_RCCL = 1
 
 
 class Geometry(C.Structure):
@@ -167,6 +174,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "csm_score_windows_dev": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "csm_score_windows_dump_dev": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "csm_resolve_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "csm_score_window_dump": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
@@ -191,6 +200,7 @@ SIGNATURES = {
     "csm_linear_solver_batch": (C.c_int, [_ctx, _P(LoopQuery), C.c_int32, _P(RefineParams), _P(RefineResult)]),
     "csm_shard_bounds": (None, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "csm_group_create": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p)]),
+    "csm_group_create_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, _P(C.c_void_p)]),
     "csm_group_destroy": (C.c_int, [C.c_void_p]),
     "csm_group_size": (C.c_int32, [C.c_void_p]),
     "csm_group_member": (C.c_void_p, [C.c_void_p, C.c_int32]),

@@ -158,11 +158,14 @@ def host_probability_lut():
 class Context:
     """One csm_ctx: owns the device grids, workspaces and a stream."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, tuning_off=0, map_uncertain_cap=0):
+        """tuning_off: L.TUNE_* bits (switch launch optimisations off: A/B runs, tests)."""
         self.lib = L.load()
         self._ctx = C.c_void_p()
         cfg = L.Config()
         cfg.device_id = device_id
+        cfg.tuning_off = tuning_off
+        cfg.map_uncertain_cap = map_uncertain_cap
         rc = self.lib.csm_create(C.byref(cfg), C.byref(self._ctx))
         if rc:
             self._ctx = C.c_void_p()
@@ -289,6 +292,16 @@ class Context:
         n, ids, wins, cols, rows = prepared
         self._check(self.lib.csm_score_windows_dev(self._ctx, n, ids, wins, cols, rows,
                                                    C.c_void_p(out_ptr)))
+
+    def score_windows_dump_dev(self, prepared, out_ptr, dump_s_ptrs, dump_k_ptrs):
+        """score_windows_dev() that also writes every candidate's integer sums of the
+        windows whose dump pointers (device, 0 = none) are given: S uint32 and K uint16,
+        [n_theta][nx][ny] each."""
+        n, ids, wins, cols, rows = prepared
+        ds = (C.c_void_p * n)(*[p or None for p in dump_s_ptrs])
+        dk = (C.c_void_p * n)(*[p or None for p in dump_k_ptrs])
+        self._check(self.lib.csm_score_windows_dump_dev(self._ctx, n, ids, wins, cols, rows,
+                                                        C.c_void_p(out_ptr), ds, dk))
 
     def correlative_match(self, map_id, geom, angles, ranges, rel_pose, init_pose,
                           range_x, range_y, range_theta, low_resolution,
@@ -484,11 +497,14 @@ class Group:
     into contiguous blocks, one host thread per member, one all-gather of the
     records (RCCL when the devices differ)."""
 
-    def __init__(self, device_ids):
+    def __init__(self, device_ids, force_rccl=False, tuning_off=0):
         self.lib = L.load()
         self._g = C.c_void_p()
         ids = np.ascontiguousarray(device_ids, dtype=np.int32)
-        rc = self.lib.csm_group_create(_ptr(ids), ids.size, C.byref(self._g))
+        cfg = L.Config()
+        cfg.tuning_off = tuning_off
+        rc = self.lib.csm_group_create_ex(_ptr(ids), ids.size, C.byref(cfg),
+                                          L.GROUP_FORCE_RCCL if force_rccl else 0, C.byref(self._g))
         if rc:
             self._g = C.c_void_p()
             raise CsmError(rc, "csm_group_create failed")

@@ -91,8 +91,26 @@ struct KernelTimer {
 
 } /* namespace */
 
+/* Launch-shape switches and forced shapes. Resolved ONCE, in csm_create: the switches from
+ * csm_config.tuning_off (CSM_TUNE_NO_*, A/B measurements and tests); the forced shapes only
+ * in tuning builds (-DCSM_TUNING, tools/build_variant.sh), from the environment. Nothing on a
+ * launch path reads the environment. */
+struct Tuning {
+    bool lane_map = true;      /* conflict-free thread -> candidate table (lane_map_for) */
+    bool xcd_map = true;       /* a job's workgroups on one XCD (xcd_block) */
+    bool pair_tail = true;     /* a window's last row block as an R = 6 launch */
+    bool two_slices = true;    /* batch fine kernel takes two theta slices per workgroup */
+    bool tile_split = true;    /* small single windows: tile list split over blockIdx.z */
+    bool map_host_projection = false;   /* map building: hit points on the host */
+    int  theta_major = -1;     /* -1: by launch size */
+    int  fine_slices = 0, force_r = 0, pair_r = 0, pair_ncbx = 0, pair_groups = 0, pair_ls = 0,
+         pair_tail_ls = 0, nbuf = 0, map_unc_cap = 0;
+    bool plan_debug = false, host_timing = false;
+};
+
 struct csm_ctx {
     int device = 0;
+    Tuning tune;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -374,7 +392,7 @@ int ilog2_exact(int v)
 
 /* Pick the candidate block (cbx wide, groups * R tall) for nx x ny candidates
  * `stride` cells apart. Fails (returns false) if nothing fits the LDS limits. */
-bool plan_pass(int nx, int ny, int stride, PassPlan* out)
+bool plan_pass(const Tuning& tune, int nx, int ny, int stride, PassPlan* out)
 {
     PassPlan p;
     p.nx = nx;
@@ -413,11 +431,10 @@ bool plan_pass(int nx, int ny, int stride, PassPlan* out)
     static const int r_strided[] = { 1, 2, 4 };
     const int* rs = strided ? r_strided : r_fine;
     const int nrs = strided ? 3 : 5;
-    const char* force = getenv("CSM_FORCE_R");   /* tuning knob */
     long best_cost = -1;
     for (int k = 0; k < nrs; ++k) {
         const int r = rs[k];
-        if (force && !strided && atoi(force) != r)
+        if (tune.force_r && !strided && tune.force_r != r)
             continue;
         if (r > max_cby)
             continue;
@@ -458,22 +475,16 @@ size_t pair_lds_bytes(int ls, int cby, int lists)
 
 /* two_slices: plan for the batch kernel that takes two theta slices per workgroup
  * (a second entry list in LDS) */
-bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
+bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two_slices = false)
 {
     const int lists = two_slices ? 2 : 1;
-    if (const char* e = getenv("CSM_PAIR_SLICES"))      /* tuning: 1 = one slice per workgroup everywhere */
-        if (atoi(e) == 1 && two_slices)
-            return plan_pass_pairs(nx, ny, out, false);
-    if (const char* e = getenv("CSM_FINE_PAIRS"))       /* tuning / fallback knob */
-        if (atoi(e) == 0)
-            return false;
+    if (!tune.two_slices && two_slices)
+        return plan_pass_pairs(tune, nx, ny, out, false);
     double best = -1.0;
     const int max_cbx = kPairLS[sizeof(kPairLS) / sizeof(kPairLS[0]) - 1] - 65;
     /* R = candidate rows per lane: 8, or 6 where that covers the rows with fewer
      * multiply-adds per wave (52 rows: 9 groups x 6 instead of 7 x 8) */
-    const int force_r = getenv("CSM_PAIR_R") ? atoi(getenv("CSM_PAIR_R")) : 0;            /* tuning knobs */
-    const int force_ncbx = getenv("CSM_PAIR_NCBX") ? atoi(getenv("CSM_PAIR_NCBX")) : 0;
-    const int force_g = getenv("CSM_PAIR_GROUPS") ? atoi(getenv("CSM_PAIR_GROUPS")) : 0;
+    const int force_r = tune.pair_r, force_ncbx = tune.pair_ncbx, force_g = tune.pair_groups;   /* tuning builds */
     for (int R : { 8, 6 })
     for (int ncbx = ceil_div(nx, max_cbx); ncbx <= ceil_div(nx, max_cbx) + 2; ++ncbx) {
         if ((force_r && R != force_r) || (force_ncbx && ncbx != force_ncbx))
@@ -525,7 +536,7 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
          * of its lanes are useful; ~450 cycles of barriers and waits */
         const double cost = (double)p.ncbx * p.ncby *
                             (0.01 * ((kTile + g * R) / 2 + 1) * p.lstride + 46.0 * (R + 6) + 450.0);
-        if (getenv("CSM_PLAN_DEBUG"))
+        if (tune.plan_debug)
             fprintf(stderr, "[plan %dx%d] R %d ncbx %d cbx %d LS %d groups %d ncby %d lds %zu cost %.0f\n", nx, ny, R,
                     ncbx, p.cbx, p.lstride, g, p.ncby, pair_lds_bytes(p.lstride, g * R, lists), cost);
         if (best < 0 || cost < best) {
@@ -535,10 +546,13 @@ bool plan_pass_pairs(int nx, int ny, PassPlan* out, bool two_slices = false)
     }
     if (best < 0)
         return false;
-    if (const char* e = getenv("CSM_PAIR_LS")) {        /* tuning: force the row pitch */
-        const int ls = atoi(e);
-        if (ls >= out->cbx + 65 && ls % 2 == 0)
-            out->lstride = ls;
+    if (tune.pair_ls) {                                 /* tuning builds: force the row pitch */
+        bool have = false;
+        for (int ls : kPairLS)
+            have = have || ls == tune.pair_ls;
+        if (have && tune.pair_ls >= out->cbx + 65 &&
+            pair_lds_bytes(tune.pair_ls, out->groups * out->R, lists) <= 160 * 1024 - 256)
+            out->lstride = tune.pair_ls;
     }
     return true;
 }
@@ -550,13 +564,12 @@ int xgrid_pad_for(int nx, int ny)
 }
 
 /* Two LDS buffers (one barrier per tile, staging overlapped with the gather)
- * when they fit; CSM_NBUF overrides for tuning. */
-int pick_buffers(size_t lds_one, long blocks)
+ * when they fit (forced in tuning builds). */
+int pick_buffers(const Tuning& tune, size_t lds_one, long blocks)
 {
     (void)blocks;
-    const char* force = getenv("CSM_NBUF");
-    if (force)
-        return atoi(force) == 2 && 2 * lds_one <= 160 * 1024 - 256 ? 2 : 1;
+    if (tune.nbuf)
+        return tune.nbuf == 2 && 2 * lds_one <= 160 * 1024 - 256 ? 2 : 1;
     /* measured (512-thread workgroups): no gain on config 2, and the halved
      * occupancy costs 25-35 % on configs 3 and 5 */
     return 1;
@@ -600,10 +613,10 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     p->y_lo = -w->win_y;
     p->x_hi = p->x_lo + p->nx - 1;
     p->y_hi = p->y_lo + p->ny - 1;
-    if (!plan_pass_pairs(p->nx, p->ny, &p->fine) && !plan_pass(p->nx, p->ny, 1, &p->fine))
+    if (!plan_pass_pairs(ctx->tune, p->nx, p->ny, &p->fine))
         return fail(ctx, CSM_EINVAL, "internal: no launch geometry for the fine level");
     p->fine.weighted = w->merge_mode == 0;
-    if (p->L > 1 && !plan_pass(p->nxc, p->nyc, p->L, &p->coarse))
+    if (p->L > 1 && !plan_pass(ctx->tune, p->nxc, p->nyc, p->L, &p->coarse))
         return fail(ctx, CSM_EINVAL, "LowResolution %d too large for the coarse kernel", p->L);
     p->tiles_x = ceil_div(g.cols - p->x_lo + p->x_hi, kTile);
     p->tiles_y = ceil_div(g.rows - p->y_lo + p->y_hi + 1, kTile);    /* + 1: k_bin's frame shift */
@@ -733,9 +746,8 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
 int lane_map_for(csm_ctx* ctx, const PassPlan& pp, const uint16_t** out)
 {
     *out = nullptr;
-    if (const char* e = getenv("CSM_LANE_MAP"))
-        if (atoi(e) == 0)
-            return CSM_OK;
+    if (!ctx->tune.lane_map)
+        return CSM_OK;
     const std::array<int, 4> key = { pp.cbx, pp.groups, pp.R, pp.lstride };
     auto it = ctx->lane_maps.find(key);
     if (it != ctx->lane_maps.end()) {
@@ -850,9 +862,9 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
         bool launched = false;
         /* a launch far larger than the chip, not tile-split: slices fastest (see k_score_pairs) */
         int theta_major = (n_slices == 1 && (long)pp.ncb() * n_theta >= 4096 && pp.ncb() <= 65535) ? 1 : 0;
-        if (const char* e = getenv("CSM_THETA_MAJOR"))
-            theta_major = (atoi(e) != 0 && n_slices == 1 && pp.ncb() <= 65535) ? 1 : 0;
-        if (theta_major && !(getenv("CSM_XCD_MAP") && atoi(getenv("CSM_XCD_MAP")) == 0))
+        if (ctx->tune.theta_major >= 0)
+            theta_major = (ctx->tune.theta_major != 0 && n_slices == 1 && pp.ncb() <= 65535) ? 1 : 0;
+        if (theta_major && ctx->tune.xcd_map)
             theta_major |= 2;        /* candidate blocks dealt to the XCDs (k_score_pairs) */
         const uint16_t* lane_map = nullptr;
         if (int rc = lane_map_for(ctx, pp, &lane_map))
@@ -867,7 +879,7 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
     size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
-    const int n_buf = pick_buffers(lds, (long)grid.x * grid.y * grid.z);
+    const int n_buf = pick_buffers(ctx->tune, lds, (long)grid.x * grid.y * grid.z);
     lds *= n_buf;
     bool launched = false;
     SCORE_DISPATCH(CALL_SINGLE);
@@ -915,10 +927,8 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
     const uint16_t* lane_map = nullptr;
     if (int rc = lane_map_for(ctx, pp, &lane_map))
         return rc;
-    /* one job's workgroups on one XCD (k_score_pairs*_batch, xcd_block); CSM_XCD_MAP=0: identity */
-    int xcd_map = 1;
-    if (const char* e = getenv("CSM_XCD_MAP"))
-        xcd_map = atoi(e) != 0;
+    /* one job's workgroups on one XCD (k_score_pairs*_batch, xcd_block); CSM_TUNE_NO_XCD_MAP: identity */
+    const int xcd_map = ctx->tune.xcd_map ? 1 : 0;
     PAIR_DISPATCH(CALL_PAIRS_BATCH);
     if (!launched)
         return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d R %d", pp.lstride, pp.R);
@@ -938,25 +948,26 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
         /* The last row block of a window rarely needs all R = 8 rows of its lanes (84 rows in
          * blocks of 48: the second block has 36). Where R = 6 covers it with the same lane
          * groups, that block is a launch of its own: three quarters of the reads and
-         * multiply-adds per entry for half of the workgroups (CSM_PAIR_TAIL=0: one launch). */
+         * multiply-adds per entry for half of the workgroups (CSM_TUNE_NO_PAIR_TAIL: one launch). */
         const int cby = pp.groups * pp.R, tail_rows = pp.ny - (pp.ncby - 1) * cby;
-        const bool split = pp.R == 8 && pp.ncby >= 2 && tail_rows > 0 && tail_rows <= pp.groups * 6 &&
-                           !(getenv("CSM_PAIR_TAIL") && atoi(getenv("CSM_PAIR_TAIL")) == 0);
+        const bool split = pp.R == 8 && pp.ncby >= 2 && tail_rows > 0 && tail_rows <= pp.groups * 6 && ctx->tune.pair_tail;
         if (!split)
             return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() });
         PassPlan tail = pp;
         tail.R = 6;
         /* its conflict-free row pitch, where one is instantiated close by (plan_pass_pairs' rule;
-         * CSM_PAIR_TAIL_LS forces a pitch for tuning) */
+         * tuning builds can force an instantiated pitch) */
         for (int ls : kPairLS)
             if (ls >= pp.lstride && ls <= pp.lstride + 8 && ((tail.R / 2) * ls - tail.cbx) % 32 == 0 &&
                 pair_lds_bytes(ls, tail.groups * tail.R, tail.lists) <= 80 * 1024 - 1024) {
                 tail.lstride = ls;
                 break;
             }
-        if (const char* e = getenv("CSM_PAIR_TAIL_LS"))
-            if (atoi(e) >= tail.cbx + 65 && atoi(e) % 2 == 0)
-                tail.lstride = atoi(e);
+        if (ctx->tune.pair_tail_ls >= tail.cbx + 65)
+            for (int ls : kPairLS)
+                if (ls == ctx->tune.pair_tail_ls &&
+                    pair_lds_bytes(ls, tail.groups * tail.R, tail.lists) <= 160 * 1024 - 256)
+                    tail.lstride = ls;
         int rc = launch_pairs_batch(ctx, jobs_dev, pp, dim3(pp.ncbx * (pp.ncby - 1), grid.y, grid.z),
                                     BlockBase{ 0, 0, pp.ncb() });
         if (rc)
@@ -968,7 +979,7 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
     size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
-    const int n_buf = pick_buffers(lds, (long)grid.x * grid.y * grid.z);
+    const int n_buf = pick_buffers(ctx->tune, lds, (long)grid.x * grid.y * grid.z);
     lds *= n_buf;
     bool launched = false;
     SCORE_DISPATCH(CALL_BATCH);
@@ -1178,14 +1189,16 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     if ((rc = ensure(ctx, ctx->sorted_rc, nt * p.n * 4))) return rc;
 
     /* tile-split fine launch when the window gives fewer than ~1.5 workgroups
-     * per CU (config 2: 246); CSM_FINE_SLICES overrides for tuning */
+     * per CU (config 2: 246); CSM_TUNE_NO_TILE_SPLIT: never */
     int fine_slices = 1;
     {
         const long blocks = (long)ncb * p.n_theta;
         if (blocks < 384)
             fine_slices = (int)std::min<long>(4, std::max<long>(1, 492 / std::max<long>(1, blocks)));
-        if (const char* e = getenv("CSM_FINE_SLICES"))
-            fine_slices = std::max(1, std::min(8, atoi(e)));
+        if (!ctx->tune.tile_split)
+            fine_slices = 1;
+        if (ctx->tune.fine_slices)
+            fine_slices = std::max(1, std::min(8, ctx->tune.fine_slices));
         if (fine_slices > 1) {
             /* the accumulators are zero between queries: cleared once when
              * (re)allocated, then by the arg-max pass as it reads them */
@@ -1561,6 +1574,42 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         return CSM_ENODEV;
     csm_ctx* ctx = new csm_ctx();
     ctx->device = dev;
+    {
+        Tuning& t = ctx->tune;
+        const uint32_t off = cfg ? cfg->tuning_off : 0u;
+        t.lane_map = !(off & CSM_TUNE_NO_LANE_MAP);
+        t.xcd_map = !(off & CSM_TUNE_NO_XCD_MAP);
+        t.pair_tail = !(off & CSM_TUNE_NO_PAIR_TAIL);
+        t.two_slices = !(off & CSM_TUNE_NO_TWO_SLICES);
+        t.tile_split = !(off & CSM_TUNE_NO_TILE_SPLIT);
+        t.map_host_projection = (off & CSM_TUNE_MAP_HOST_PROJECTION) != 0;
+        if (off & CSM_TUNE_NO_THETA_MAJOR)
+            t.theta_major = 0;
+        t.map_unc_cap = cfg ? cfg->map_uncertain_cap : 0;
+#ifdef CSM_TUNING
+        /* tuning builds only (tools/build_variant.sh): forced launch shapes from the environment,
+         * read here once -- never on a launch path */
+        auto env_int = [](const char* name, int dflt) {
+            const char* e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        t.lane_map = env_int("CSM_LANE_MAP", t.lane_map) != 0;
+        t.xcd_map = env_int("CSM_XCD_MAP", t.xcd_map) != 0;
+        t.pair_tail = env_int("CSM_PAIR_TAIL", t.pair_tail) != 0;
+        t.two_slices = env_int("CSM_PAIR_SLICES", t.two_slices ? 2 : 1) != 1;
+        t.theta_major = env_int("CSM_THETA_MAJOR", t.theta_major);
+        t.fine_slices = env_int("CSM_FINE_SLICES", 0);
+        t.force_r = env_int("CSM_FORCE_R", 0);
+        t.pair_r = env_int("CSM_PAIR_R", 0);
+        t.pair_ncbx = env_int("CSM_PAIR_NCBX", 0);
+        t.pair_groups = env_int("CSM_PAIR_GROUPS", 0);
+        t.pair_ls = env_int("CSM_PAIR_LS", 0);
+        t.pair_tail_ls = env_int("CSM_PAIR_TAIL_LS", 0);
+        t.nbuf = env_int("CSM_NBUF", 0);
+        t.plan_debug = env_int("CSM_PLAN_DEBUG", 0) != 0;
+        t.host_timing = env_int("CSM_HOST_TIMING", 0) != 0;
+#endif
+    }
     if (hipSetDevice(dev) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -2312,6 +2361,8 @@ struct ResidentBatch {
     const int32_t* const* hit_col;        /* [n] device pointers, [n_theta][n_points] each */
     const int32_t* const* hit_row;
     csm_result* out_dev;                  /* [n] device */
+    uint32_t* const* dump_s = nullptr;    /* optional [n] device pointers (any may be null): every candidate's */
+    uint16_t* const* dump_k = nullptr;    /* integer sums, [n_theta][nx][ny] (parity tests) */
 };
 
 /* One group of queries that share (nx, ny): the whole device pipeline. */
@@ -2321,7 +2372,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
 {
     const int H = spec.H;
     const int nq = (int)idx.size();
-    const bool host_timing = getenv("CSM_HOST_TIMING") != nullptr;
+    const bool host_timing = ctx->tune.host_timing;
     auto tick = [&](const char* what) {
         static thread_local std::chrono::steady_clock::time_point last;
         const auto now = std::chrono::steady_clock::now();
@@ -2447,9 +2498,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     /* ---- launch geometry shared by the group ---- */
     std::vector<PassPlan> lp(H + 1);
     for (int h = 0; h <= H; ++h) {
-        if (h == 0 && plan_pass_pairs(nx, ny, &lp[0], true))
+        if (h == 0 && plan_pass_pairs(ctx->tune, nx, ny, &lp[0], true))
             continue;
-        if (!plan_pass(nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
+        if (!plan_pass(ctx->tune, nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
             return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
                         spec.stride[h]);
     }
@@ -2638,6 +2689,10 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         F.ny = ny;
         F.stride = 1;
         F.block_best = d_best + p.best_off;
+        if (resident && resident->dump_s)
+            F.dump_s = resident->dump_s[idx[k]];
+        if (resident && resident->dump_k)
+            F.dump_k = resident->dump_k[idx[k]];
         /* branch and bound tests every popped node, leaf included; the
          * correlative sweep tests the coarse node only */
         F.check_own_known = spec.bnb || H == 0;
@@ -2856,7 +2911,7 @@ int csm_bnb_match_batch(csm_ctx* ctx, const csm_loop_query* queries, int32_t n_q
         return fail(ctx, CSM_EINVAL, "csm_bnb_match_batch: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int H = prm->node_height_max;
-    const bool host_timing = getenv("CSM_HOST_TIMING") != nullptr;
+    const bool host_timing = ctx->tune.host_timing;
     const auto tb0 = std::chrono::steady_clock::now();
     {
         int rc = begin_batch_records(ctx, n_queries);
@@ -3150,6 +3205,14 @@ int csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, cons
                           const int32_t* const* hit_col_dev, const int32_t* const* hit_row_dev,
                           csm_result* out_dev)
 {
+    return csm_score_windows_dump_dev(ctx, n, map_ids, windows, hit_col_dev, hit_row_dev, out_dev, nullptr,
+                                      nullptr);
+}
+
+int csm_score_windows_dump_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, const csm_window* windows,
+                               const int32_t* const* hit_col_dev, const int32_t* const* hit_row_dev,
+                               csm_result* out_dev, uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev)
+{
     if (!ctx || n < 1 || !map_ids || !windows || !hit_col_dev || !hit_row_dev || !out_dev)
         return fail(ctx, CSM_EINVAL, "csm_score_windows_dev: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3179,7 +3242,7 @@ int csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, cons
         const int nx = ceil_div(2 * w.win_x + 1, L) * L, ny = ceil_div(2 * w.win_y + 1, L) * L;
         groups[{ nx, ny, L, w.merge_mode }].push_back(i);
     }
-    ResidentBatch resident { windows, hit_col_dev, hit_row_dev, out_dev };
+    ResidentBatch resident { windows, hit_col_dev, hit_row_dev, out_dev, dump_s_dev, dump_k_dev };
     /* drop the tables of earlier calls whose launch chains have completed */
     while (!ctx->resident_hold.empty()) {
         const bool full = ctx->resident_hold.size() >= 256;

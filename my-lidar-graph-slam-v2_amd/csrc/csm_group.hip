@@ -155,6 +155,12 @@ void csm_shard_bounds(int32_t n_queries, int32_t member, int32_t n_members, int3
 
 int csm_group_create(const int32_t* device_ids, int32_t n_devices, csm_group** out)
 {
+    return csm_group_create_ex(device_ids, n_devices, nullptr, 0u, out);
+}
+
+int csm_group_create_ex(const int32_t* device_ids, int32_t n_devices, const csm_config* member_cfg,
+                        uint32_t flags, csm_group** out)
+{
     if (!out)
         return CSM_EINVAL;
     *out = nullptr;
@@ -163,6 +169,8 @@ int csm_group_create(const int32_t* device_ids, int32_t n_devices, csm_group** o
     csm_group* g = new csm_group();
     for (int k = 0; k < n_devices; ++k) {
         csm_config cfg {};
+        if (member_cfg)
+            cfg = *member_cfg;
         cfg.device_id = device_ids[k];
         csm_ctx* ctx = nullptr;
         const int rc = csm_create(&cfg, &ctx);
@@ -177,11 +185,10 @@ int csm_group_create(const int32_t* device_ids, int32_t n_devices, csm_group** o
     }
     std::set<int> uniq(g->devices.begin(), g->devices.end());
     g->distinct = uniq.size() == g->devices.size();
-    /* RCCL when the members sit on different devices; CSM_GROUP_FORCE_RCCL=1 also
-     * takes it for a single member (a one-rank communicator: exercises the RCCL
-     * call sequence on a one-GPU box) */
-    const char* force = getenv("CSM_GROUP_FORCE_RCCL");
-    g->use_rccl = g->distinct && (n_devices > 1 || (force && atoi(force) == 1));
+    /* RCCL when the members sit on different devices; CSM_GROUP_FORCE_RCCL also takes it
+     * for a single member (a one-rank communicator: exercises the RCCL call sequence on
+     * a one-GPU box) */
+    g->use_rccl = g->distinct && (n_devices > 1 || (flags & CSM_GROUP_FORCE_RCCL));
     g->send.resize(n_devices);
     g->recv.resize(n_devices);
     *out = g;

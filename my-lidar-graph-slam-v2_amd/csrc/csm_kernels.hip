@@ -1210,7 +1210,12 @@ __device__ __forceinline__ void pairs_gather(uint32_t lane_addr, const uint32_t*
         const unsigned long long heavy = __builtin_amdgcn_ballot_w64(b > 8);
         flags = __builtin_amdgcn_ballot_w64(cross) | heavy | heavy << 1 | heavy << 2 | heavy << 3 | heavy << 4 |
                 (fs.carry ? 0xfull : 0ull);
-        fs.carry = (heavy >> 60) != 0;
+        /* a heavy entry among the last four REAL entries of this chunk flags the first group
+         * of the next chunk -- also when that chunk is the next tile's list (acc[] and cum
+         * live on across tiles, and a list normally ends in a partial chunk: looking at
+         * lanes 60..63 only lost the flag there and let 152 beams pile up) */
+        const int last = min(64, cnt - j0);
+        fs.carry = (heavy >> max(0, last - 4)) != 0;
         fs.cum = __builtin_amdgcn_readlane(c1, 63) % 96;
     };
     int j = 0;

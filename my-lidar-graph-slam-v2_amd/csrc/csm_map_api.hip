@@ -191,10 +191,10 @@ static int map_build(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape,
     };
     for (const MapNode& t : table)
         add_point(t.x, t.y);
-    bool device_projection = n_beams > 0 && !std::getenv("CSM_MAP_HOST_PROJECTION");
+    bool device_projection = n_beams > 0 && !ctx->tune.map_host_projection;
     uint32_t unc_cap = kMapUncCap;
-    if (const char* e = std::getenv("CSM_MAP_UNC_CAP"))     /* test knob */
-        unc_cap = (uint32_t)std::min<long>(std::max<long>(std::atol(e), 0), kMapUncCap);
+    if (ctx->tune.map_unc_cap > 0)          /* csm_config.map_uncertain_cap: tests of the overflow path */
+        unc_cap = (uint32_t)std::min<long>(ctx->tune.map_unc_cap, kMapUncCap);
     bool spread_known = false;              /* the box of the certified beams is certainly not degenerate */
     if (device_projection) {
         /* scans to the device (one staging copy), projection there */

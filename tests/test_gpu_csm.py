@@ -7,7 +7,7 @@ import math
 import numpy as np
 import pytest
 
-from csm_hip import api, synth
+from csm_hip import _lib as Lb, api, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -112,21 +112,87 @@ def test_saturated_grid_never_overflows_the_packed_accumulators(gpu_ctx, oracle,
     gpu_ctx.release_grid(3)
 
 
-def test_lane_table_on_and_off_give_identical_sums(gpu_ctx, oracle, monkeypatch):
+def test_lane_table_on_and_off_give_identical_sums(gpu_ctx, oracle):
     """The pair kernels take the thread -> (lane group, column) assignment from a host
     table that keeps half-waves free of LDS bank conflicts (lane_map_for, csm_api.hip);
-    CSM_LANE_MAP=0 numbers the threads through the groups in order. Both must give every
-    candidate's sums (84 x 84 window: 6 groups of 84 columns, the shape the table is for)."""
+    CSM_TUNE_NO_LANE_MAP numbers the threads through the groups in order. Both must give
+    every candidate's sums (84 x 84 window: 6 groups of 84 columns, the shape the table is for)."""
     case = synth.csm_case(21, n_beams=1080, fov=1.5 * math.pi)
     rx, ry, rt, L = 2.0, 2.0, math.radians(4), 4
     (wx, wy, wt), col, row, mk = _window_for(case, rx, ry, rt, L)
-    gpu_ctx.upload_grid(4, case["grid"])
-    gpu_ctx.build_pyramid(4, [1, L])
-    w = gpu_ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, L, 1, mk, 0.0)
     want, oS, oK, oCK = oracle.csm_closed_form(case, rx, ry, rt, L, dump=True)
-    for setting in ("1", "0"):
-        monkeypatch.setenv("CSM_LANE_MAP", setting)
-        res, S, K, CK = gpu_ctx.score_window(4, w, col, row, dump=True)
-        assert np.array_equal(S, oS) and np.array_equal(K, oK), setting
+    plain = api.Context(0, tuning_off=Lb.TUNE_NO_LANE_MAP)
+    for ctx in (gpu_ctx, plain):
+        ctx.upload_grid(4, case["grid"])
+        ctx.build_pyramid(4, [1, L])
+        w = ctx.make_window(2 * wt + 1, len(case["angles"]), wx, wy, L, 1, mk, 0.0)
+        res, S, K, CK = ctx.score_window(4, w, col, row, dump=True)
+        assert np.array_equal(S, oS) and np.array_equal(K, oK)
         assert (res["best_x"], res["best_y"], res["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"])
-    gpu_ctx.release_grid(4)
+        ctx.release_grid(4)
+    plain.close()
+
+
+def _carry_case(n_theta):
+    """Hit indices (the same for every slice) that put, on an all-65535 grid and an 84 x 84
+    window, exactly the entry sequence that once lost a flush: the first endpoint tile holds
+    36 one-beam even-row entries and then four 15-beam odd-row entries (the heavy group is
+    flushed at its start, leaves 60 beams in the packed accumulators and the running count at
+    a multiple of 96), the next tile 96 one-beam entries whose first bucket boundary is entry
+    95. Without the carry of "heavy entry among the last four" across the tile boundary 152
+    beams pile up before the next flush and the value sum (23 bits) runs into the count."""
+    win, n_cand = 40, 84                      # nx = ny = 84 for L = 4
+    x_hi = y_hi = -win + n_cand - 1           # 43; k_bin's frame: rr = r + y_hi + 1, cc = c + x_hi
+    cells = []                                # (frame row, frame col, beams)
+    cells += [(140, 130 + i, 1) for i in range(36)]
+    cells += [(143, 130 + i, 15) for i in range(4)]
+    cells += [(200, 128 + i, 1) for i in range(64)] + [(202, 128 + i, 1) for i in range(32)]
+    row = np.concatenate([[rr - y_hi - 1] * m for rr, cc, m in cells]).astype(np.int32)
+    col = np.concatenate([[cc - x_hi] * m for rr, cc, m in cells]).astype(np.int32)
+    return win, np.tile(col, (n_theta, 1)), np.tile(row, (n_theta, 1))
+
+
+def test_flush_carry_across_tile_boundary_single_window(gpu_ctx):
+    """pairs_gather's carry across lists. Single-window kernel, not
+    tile-split (2 x 193 workgroups >= 384), full S / K dump: every candidate sees all 192
+    beams on saturated cells."""
+    n_theta = 193
+    win, col, row = _carry_case(n_theta)
+    n = col.shape[1]
+    assert n == 36 + 60 + 96
+    grid = np.full((400, 400), 65535, np.uint16)
+    gpu_ctx.upload_grid(5, grid)
+    gpu_ctx.build_pyramid(5, [1, 4])
+    w = gpu_ctx.make_window(n_theta, n, win, win, 4, 1, 0, 0.0)
+    res, S, K, CK = gpu_ctx.score_window(5, w, col, row, dump=True)
+    assert int(K.min()) == int(K.max()) == n
+    assert int(S.min()) == int(S.max()) == 65535 * n
+    gpu_ctx.release_grid(5)
+
+
+def test_flush_carry_across_tile_boundary_batch(gpu_ctx):
+    """The same sequence through the batched two-slice kernel (csm_score_windows_dump_dev)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_theta = 9
+    win, col, row = _carry_case(n_theta)
+    n = col.shape[1]
+    ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.upload_grid(6, np.full((400, 400), 65535, np.uint16))
+    ctx.build_pyramid(6, [1, 4])
+    nw = 3
+    w = ctx.make_window(n_theta, n, win, win, 4, 1, 0, 0.0)
+    c_d, r_d = torch.from_numpy(col).to(dev), torch.from_numpy(row).to(dev)
+    out = torch.zeros(nw * 48, dtype=torch.uint8, device=dev)
+    ds = [torch.zeros(n_theta * 84 * 84, dtype=torch.int32, device=dev) for _ in range(nw)]
+    dk = [torch.zeros(n_theta * 84 * 84, dtype=torch.int16, device=dev) for _ in range(nw)]
+    prepared = ctx.prepare_windows([6] * nw, [w] * nw, [c_d.data_ptr()] * nw, [r_d.data_ptr()] * nw)
+    ctx.score_windows_dump_dev(prepared, out.data_ptr(), [t.data_ptr() for t in ds], [t.data_ptr() for t in dk])
+    torch.cuda.synchronize(dev)
+    for k in range(nw):
+        S = ds[k].cpu().numpy().view(np.uint32)
+        K = dk[k].cpu().numpy().view(np.uint16)
+        assert int(K.min()) == int(K.max()) == n, k
+        assert int(S.min()) == int(S.max()) == 65535 * n, k
+    ctx.close()

@@ -44,12 +44,7 @@ def reference():
 @pytest.mark.parametrize("devices,force_rccl", [([0], False), ([0, 0], False), ([0, 0, 0], False), ([0], True)])
 def test_group_equals_single_context(reference, devices, force_rccl):
     queries, grids, want = reference
-    if force_rccl:
-        os.environ["CSM_GROUP_FORCE_RCCL"] = "1"
-    try:
-        grp = api.Group(devices)
-    finally:
-        os.environ.pop("CSM_GROUP_FORCE_RCCL", None)
+    grp = api.Group(devices, force_rccl=force_rccl)
     assert len(grp.members) == len(devices)
     used_rccl, _ = grp.exchange_info()
     assert used_rccl == force_rccl

@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from csm_hip import api, synth
+from csm_hip import _lib as L, api, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -133,19 +133,20 @@ def test_map_randomised(gpu_ctx, oracle, seed):
     gpu_ctx.release_grid(400 + seed)
 
 
-def test_map_projection_paths(gpu_ctx, oracle, monkeypatch):
+def test_map_projection_paths(gpu_ctx, oracle):
     """The hit points come from the device under a certificate; forcing the host
     projection must give the same map."""
     case = synth.map_case(31, n_scans=5, n_beams=500, noise=0.01)
     _, grid, info = _check(gpu_ctx, oracle, case, 450)
     assert info["device_projection"] == 1
-    monkeypatch.setenv("CSM_MAP_HOST_PROJECTION", "1")
-    _, grid2, info2 = _check(gpu_ctx, oracle, case, 450)
+    host_ctx = api.Context(0, tuning_off=L.TUNE_MAP_HOST_PROJECTION)
+    _, grid2, info2 = _check(host_ctx, oracle, case, 450)
     assert info2["device_projection"] == 0 and np.array_equal(grid, grid2)
+    host_ctx.close()
     gpu_ctx.release_grid(450)
 
 
-def test_map_aligned_geometry(gpu_ctx, oracle, monkeypatch):
+def test_map_aligned_geometry(gpu_ctx, oracle):
     """Sensor and walls on exact multiples of the resolution: hit points on cell
     edges (the device cannot certify them: they are redone on the host, or, past
     the list's capacity, everything is), rays through cell corners."""
@@ -160,9 +161,10 @@ def test_map_aligned_geometry(gpu_ctx, oracle, monkeypatch):
     for scale in (1, 2, 100):
         _, _, info = _check(gpu_ctx, oracle, case, 440, subpixel_scale=scale)
         assert info["device_projection"] == 1
-    monkeypatch.setenv("CSM_MAP_UNC_CAP", "3")
-    _, _, info = _check(gpu_ctx, oracle, case, 440, subpixel_scale=100)
+    small = api.Context(0, map_uncertain_cap=3)
+    _, _, info = _check(small, oracle, case, 440, subpixel_scale=100)
     assert info["device_projection"] == 0           # more than 3 beams sit on cell edges
+    small.close()
     gpu_ctx.release_grid(440)
 
 
