@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "csm_kernels.hip"
+#include "csm_joint.hpp"
 #include "csm_map_kernels.hip"
 #include "csm_cost_kernels.hip"
 
@@ -100,6 +101,7 @@ struct Tuning {
     bool xcd_map = true;       /* a job's workgroups on one XCD (xcd_block) */
     bool pair_tail = true;     /* a window's last row block as an R = 6 launch */
     bool two_slices = true;    /* batch fine kernel takes two theta slices per workgroup */
+    bool joint = true;         /* ... on joint entry lists of the two slices (k_binj / k_score_joint_batch) */
     bool tile_split = true;    /* small single windows: tile list split over blockIdx.z */
     bool map_host_projection = false;   /* map building: hit points on the host */
     int  theta_major = -1;     /* -1: by launch size */
@@ -379,6 +381,7 @@ struct PassPlan {
     bool weighted = true;     /* entries carry beam multiplicities */
     bool pairs = false;       /* pair-row fine kernel (k_score_pairs): lstride = slots per pair row */
     int lists = 1;            /* entry lists in LDS: 2 = the batch kernel that takes two slices per workgroup */
+    bool joint = false;       /* ... on joint entries of the two slices (one list; csm_joint_kernels.hip) */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -929,6 +932,29 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
         return rc;
     /* one job's workgroups on one XCD (k_score_pairs*_batch, xcd_block); CSM_TUNE_NO_XCD_MAP: identity */
     const int xcd_map = ctx->tune.xcd_map ? 1 : 0;
+    if (pp.joint) {
+        csm::JointLaunch L;
+        L.stream = ctx->stream;
+        L.device = ctx->device;
+        L.jobs_dev = jobs_dev;
+        L.grid = dim3(grid.x, (grid.y + 1) / 2, grid.z);
+        L.lds_bytes = lds;
+        L.ls = pp.lstride;
+        L.R = pp.R;
+        L.cbx = pp.cbx;
+        L.groups = pp.groups;
+        L.lane_map = lane_map;
+        L.xcd_map = xcd_map;
+        L.row_base = bb.row_base;
+        L.cb_base = bb.cb_base;
+        L.ncb = bb.ncb;
+        const int e = csm::launch_joint_batch(L);
+        if (e < 0)
+            return fail(ctx, CSM_EINVAL, "internal: no joint kernel for LS %d R %d", pp.lstride, pp.R);
+        if (e != 0)
+            return fail(ctx, CSM_EIO, "joint fine kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        return CSM_OK;
+    }
     PAIR_DISPATCH(CALL_PAIRS_BATCH);
     if (!launched)
         return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d R %d", pp.lstride, pp.R);
@@ -955,19 +981,11 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
             return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() });
         PassPlan tail = pp;
         tail.R = 6;
-        /* its conflict-free row pitch, where one is instantiated close by (plan_pass_pairs' rule;
-         * tuning builds can force an instantiated pitch) */
-        for (int ls : kPairLS)
-            if (ls >= pp.lstride && ls <= pp.lstride + 8 && ((tail.R / 2) * ls - tail.cbx) % 32 == 0 &&
-                pair_lds_bytes(ls, tail.groups * tail.R, tail.lists) <= 80 * 1024 - 1024) {
-                tail.lstride = ls;
-                break;
-            }
-        if (ctx->tune.pair_tail_ls >= tail.cbx + 65)
-            for (int ls : kPairLS)
-                if (ls == ctx->tune.pair_tail_ls &&
-                    pair_lds_bytes(ls, tail.groups * tail.R, tail.lists) <= 160 * 1024 - 256)
-                    tail.lstride = ls;
+        /* The tail launch keeps the main launch's row pitch: k_bin wrote the entries' LDS offsets
+         * for THAT pitch (BinJob.lstride). Round 2's last commit gave the tail its own
+         * conflict-free pitch (156 instead of 150) and thereby scored candidate rows 48..83 of
+         * every window on the wrong cells -- unnoticed because winners sit near the window's
+         * centre; tests/test_gpu_headline.py (full S / K dumps of this launch shape) found it. */
         int rc = launch_pairs_batch(ctx, jobs_dev, pp, dim3(pp.ncbx * (pp.ncby - 1), grid.y, grid.z),
                                     BlockBase{ 0, 0, pp.ncb() });
         if (rc)
@@ -1581,6 +1599,7 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.xcd_map = !(off & CSM_TUNE_NO_XCD_MAP);
         t.pair_tail = !(off & CSM_TUNE_NO_PAIR_TAIL);
         t.two_slices = !(off & CSM_TUNE_NO_TWO_SLICES);
+        t.joint = !(off & CSM_TUNE_NO_JOINT);
         t.tile_split = !(off & CSM_TUNE_NO_TILE_SPLIT);
         t.map_host_projection = (off & CSM_TUNE_MAP_HOST_PROJECTION) != 0;
         if (off & CSM_TUNE_NO_THETA_MAJOR)
@@ -1597,6 +1616,7 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.xcd_map = env_int("CSM_XCD_MAP", t.xcd_map) != 0;
         t.pair_tail = env_int("CSM_PAIR_TAIL", t.pair_tail) != 0;
         t.two_slices = env_int("CSM_PAIR_SLICES", t.two_slices ? 2 : 1) != 1;
+        t.joint = env_int("CSM_JOINT", t.joint) != 0;
         t.theta_major = env_int("CSM_THETA_MAJOR", t.theta_major);
         t.fine_slices = env_int("CSM_FINE_SLICES", 0);
         t.force_r = env_int("CSM_FORCE_R", 0);
@@ -2423,22 +2443,55 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         p.ny = ceil_div(2 * p.win_y + 1, big) * big;
         p.tiles_x = ceil_div(p.grid->cols + p.win_x + (-p.win_x + p.nx - 1), kTile);
         p.tiles_y = ceil_div(p.grid->rows + p.win_y + (-p.win_y + p.ny - 1) + 1, kTile);
-        p.max_tiles = std::min(p.n, p.tiles_x * p.tiles_y) + p.n / kPbMax + 1;
         if (p.n > kMaxPoints)
             return fail(ctx, CSM_EINVAL, "query %d: more than %d beams per scan", idx[k], kMaxPoints);
+        n_theta_max = std::max(n_theta_max, p.n_theta);
+        n_points_max = std::max(n_points_max, p.n);
+    }
+    const int nx = pp[0].nx, ny = pp[0].ny;
+
+    /* ---- launch geometry shared by the group ---- */
+    std::vector<PassPlan> lp(H + 1);
+    for (int h = 0; h <= H; ++h) {
+        if (h == 0 && plan_pass_pairs(ctx->tune, nx, ny, &lp[0], true))
+            continue;
+        if (!plan_pass(ctx->tune, nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
+            return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
+                        spec.stride[h]);
+    }
+    if (resident) {
+        lp[0].weighted = resident->windows[idx[0]].merge_mode == 0;
+    } else {
+        const csm_loop_query& q0 = queries[idx[0]];
+        lp[0].weighted = merging_pays(q0.scan.angles, q0.scan.ranges, q0.scan.n_points,
+                                      q0.geometry.resolution);
+    }
+    /* Joint entry lists of slice pairs (k_binj + k_score_joint_batch, csm_joint_kernels.hip): the
+     * two-slice plan with merged (weighted) entries, when the joint hash table of every query
+     * leaves room for two binning workgroups (8 waves each) per CU. Otherwise round 2's per-slice lists. */
+    size_t binj_lds = 0;
+    for (int k = 0; k < nq; ++k)
+        binj_lds = std::max(binj_lds, csm::binj_lds_bytes(pp[k].tiles_x * pp[k].tiles_y, pp[k].n,
+                                                          bin_hash_size(2 * pp[k].n)));
+    const bool joint = ctx->tune.joint && lp[0].pairs && lp[0].lists == 2 && lp[0].weighted &&
+                       binj_lds <= 78 * 1024;      /* two binning workgroups per CU */
+    lp[0].joint = joint;
+    for (int k = 0; k < nq; ++k) {
+        BatchPrep& p = pp[k];
+        /* lists and records per slice, or per pair of slices (2 n entries each) */
+        const int units = joint ? (p.n_theta + 1) / 2 : p.n_theta;
+        const int per_unit = joint ? 2 * p.n : p.n;
+        p.max_tiles = std::min(per_unit, p.tiles_x * p.tiles_y) + per_unit / kPbMax + 1;
         bin_lds = std::max(bin_lds, bin_lds_bytes(p.tiles_x * p.tiles_y, p.n));
         p.hit_off = hit_total;
         p.tile_off = tile_total;
         p.theta_off = theta_total;
-        hit_total += (size_t)p.n_theta * p.n;
-        tile_total += (size_t)p.n_theta * p.max_tiles;
+        hit_total += (size_t)(p.n_theta + 1) * p.n;         /* >= units * per_unit */
+        tile_total += (size_t)units * p.max_tiles;
         theta_total += 2 * (size_t)p.n_theta;     /* record counts + merge flags */
-        n_theta_max = std::max(n_theta_max, p.n_theta);
-        n_points_max = std::max(n_points_max, p.n);
     }
     if (bin_lds > 160 * 1024 - 64)
         return fail(ctx, CSM_EINVAL, "grid + window too large for the binning kernel (its per-tile words, hash table and cell list exceed the LDS)");
-    const int nx = pp[0].nx, ny = pp[0].ny;
 
     /* scans go to the device as they are (angles, ranges); the projection runs
      * there with a per-entry certificate (k_project) */
@@ -2495,22 +2548,6 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     }
 
     tick("setup");
-    /* ---- launch geometry shared by the group ---- */
-    std::vector<PassPlan> lp(H + 1);
-    for (int h = 0; h <= H; ++h) {
-        if (h == 0 && plan_pass_pairs(ctx->tune, nx, ny, &lp[0], true))
-            continue;
-        if (!plan_pass(ctx->tune, nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
-            return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
-                        spec.stride[h]);
-    }
-    if (resident) {
-        lp[0].weighted = resident->windows[idx[0]].merge_mode == 0;
-    } else {
-        const csm_loop_query& q0 = queries[idx[0]];
-        lp[0].weighted = merging_pays(q0.scan.angles, q0.scan.ranges, q0.scan.n_points,
-                                      q0.geometry.resolution);
-    }
     const int lstride = lp[0].lstride;
     const int ncb = lp[0].ncb();
 
@@ -2623,10 +2660,10 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.tiles_y = p.tiles_y;
         B.known_r0 = g.known_r0;
         B.known_c0 = g.known_c0;
-        B.hash_size = bin_hash_size(p.n);
+        B.hash_size = bin_hash_size(joint ? 2 * p.n : p.n);
         B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
-        B.pair_mode = lp[0].pairs ? 1 : 0;
+        B.pair_mode = joint ? 2 : lp[0].pairs ? 1 : 0;
 #ifdef CSM_BIN_TIMING
         B.tuning_counters = bin_debug_buffer();
 #endif
@@ -2653,6 +2690,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         base.y_lo = y_lo;
         base.flags = d_flags + k;
         base.min_known = min_known;
+        base.joint = joint ? 1 : 0;
         base.rank_l = spec.bnb ? 1 : spec.unit;
         for (int h = 1; h <= H; ++h) {
             ScoreJob& S = sj[h][k];
@@ -2790,7 +2828,13 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
                            dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ProjJob*>(d_ij));
         HIP_TRY(ctx, hipGetLastError());
     }
-    {
+    if (joint) {
+        ScopedTimer tm(ctx, "bin");
+        const int e = csm::launch_binj_batch(ctx->stream, ctx->device, reinterpret_cast<const BinJob*>(d_bj),
+                                             (n_theta_max + 1) / 2, nq, binj_lds);
+        if (e != 0)
+            return fail(ctx, CSM_EIO, "joint binning launch failed: %s", hipGetErrorString((hipError_t)e));
+    } else {
         if ((rc = set_lds(ctx, k_bin_batch, bin_lds))) return rc;
         ScopedTimer tm(ctx, "bin");
         hipLaunchKernelGGL(k_bin_batch, dim3(n_theta_max, nq), dim3(kBinBlock), bin_lds, ctx->stream,

@@ -74,7 +74,8 @@ struct BinJob {
     int32_t hash_size;         /* power of two >= 4/3 n_points (LDS hash table of k_bin) */
     int32_t max_mult;          /* kMaxMult: merge same-cell beams; 1: one entry per beam */
     int32_t lstride;
-    int32_t pair_mode;         /* entries are aligned row pairs (pair-row fine kernel) */
+    int32_t pair_mode;         /* 1: entries are aligned row pairs (pair-row fine kernel); 2: joint
+                                  entries of two slices (k_binj: lists and records per pair of slices) */
     int32_t frame_shift;       /* 0 / 1 added to the tile frame's row origin: (y_lo + y_hi + shift) even,
                                   so that frame parity == grid-row parity of what the fine kernel reads */
     /* first row / column of the map that holds a known cell: a box that ends
@@ -112,7 +113,9 @@ struct ScoreJob {
      * every side, xg_pitch slots per pair row (k_expand_pairs) */
     const uint32_t* xg;
     int32_t xg_pitch, xg_pad;
-    int32_t pad0;
+    int32_t joint;             /* entry lists, records and record counts are per PAIR of theta slices
+                                  (k_binj, csm_joint_kernels.hip): index t / 2, 2 n_points entries per
+                                  pair, four beam counts per entry */
     const uint32_t* sorted_pb;
     const TileRec*  tiles;
     const int32_t*  n_tiles;

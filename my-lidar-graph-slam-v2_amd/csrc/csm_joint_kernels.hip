@@ -1,0 +1,705 @@
+/* csm_joint_kernels.hip -- the batched fine level on JOINT entries of two neighbouring
+ * theta slices (round 3). A translation unit of its own inside libcsm_hip.so.
+ *
+ * Why. Slices 2p and 2p + 1 are 0.25 - 0.5 degrees apart: four fifths of the (row pair,
+ * column) slots one of them hits are hit by the other too (configs[1]: 480 pair entries per
+ * slice, 533 in the union of two slices). Round 2's batch kernel (k_score_pairs2_batch)
+ * already staged ONE window per tile for the two slices but walked two entry lists: every
+ * shared slot was read from LDS twice (R/2 + 1 ds_read_b64 each time), decoded twice, and
+ * the lists came sorted by three classes whose 1 - 3 left-over entries ran through a loop
+ * of single, latency-exposed entries. Here k_binj bins the beams of BOTH slices into one
+ * hash table, an entry is a slot with four beam counts
+ *     (even row, slice 0) (odd row, slice 0) (even row, slice 1) (odd row, slice 1)
+ * and the gather reads the slot's R/2 + 1 row pairs once and feeds both accumulator sets:
+ * 45 % fewer LDS reads and address / decode instructions per launch, no classes, no class
+ * tails. A count of zero skips its R multiply-adds by a scalar branch inside the inline
+ * assembly block (s_bfe_u32 sets SCC; the compiler sees one straight-line block, so the
+ * hand-issued reads in flight never cross a basic-block edge).
+ *
+ * Replaces the sweep of src/mapping/scan_matcher_correlative.cpp:161-197, 301-368 and
+ * ScorePixelAccurate::Score per leaf (src/mapping/score_function_pixel_accurate.cpp:16-58)
+ * for batches; exact integer (S, K) per candidate as before.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "csm_score_common.hpp"
+#include "csm_joint.hpp"
+
+namespace csm {
+
+/* ------------------------------------------------------------------ K0, joint */
+constexpr int kBinjBlock = 512;      /* threads per workgroup of the joint binning kernel: its hash table
+                                        (12 B per slot, 4096 slots for 2 x 1080 beams) allows two
+                                        workgroups per CU, so each brings 8 waves */
+
+/* One workgroup (kBinjBlock threads) per PAIR of theta slices (2p, 2p + 1; the last pair of
+ * an odd number of slices holds one). Entry words:
+ *   sorted_pb: m_o1 << 28 | m_e1 << 24 | m_o0 << 20 | m_e0 << 16 | slot
+ *              slot = pair_row * lstride + col inside the tile's bounding box (< 16384)
+ *   sorted_rc: the same counts | row << 7 | col (row even, rows / cols inside the bounding
+ *              box; the strided kernels of the coarser levels pick the counts of their slice)
+ * Lists, records and record counts are indexed by the pair: sorted_pb + p * 2 n_points,
+ * tiles + p * max_tiles, n_tiles[p]. The structure follows k_bin (csm_kernels.hip): an LDS
+ * hash table keyed by (tile, row pair, column), runs of neighbouring lanes with one key
+ * inserted once, the probes of kAhead iterations travelling together, a list of the slots
+ * claimed (a wave appends its new slots behind one LDS counter). No classes: one count per tile. */
+__device__ __forceinline__ void k_binj_body(const BinJob& job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm_binj[];
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int tiles_x = uni(job.tiles_x);
+    const int ntile = tiles_x * uni(job.tiles_y);
+    const int hash_size = uni(job.hash_size);
+    const int n_theta_job = uni(job.n_theta);
+    const int p = blockIdx.x;
+    const int t0 = 2 * p;
+    if (t0 >= n_theta_job)
+        return;
+    const int n = uni(job.n_points);
+    const int n2 = t0 + 1 < n_theta_job ? 2 * n : n;         /* beams of this pair */
+    const int ntp = (ntile + 1) & ~1;
+    unsigned long long* rowmask = reinterpret_cast<unsigned long long*>(sm_binj);      /* [ntp] */
+    unsigned long long* colmask = rowmask + ntp;                                       /* [ntp] */
+    unsigned long long* hval = colmask + ntp;        /* [hash_size] beams: e0 | o0 << 16 | e1 << 32 | o1 << 48 */
+    uint32_t* hkey = reinterpret_cast<uint32_t*>(hval + hash_size);   /* [hash_size] (tile, cell) + 1, 0 = empty */
+    uint32_t* cnt = hkey + hash_size;                /* [ntp] entries of the tile, later its cursor */
+    uint16_t* list = reinterpret_cast<uint16_t*>(cnt + ntp);          /* [n2] occupied slots */
+    __shared__ uint32_t list_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    /* slices t0 and t0 + 1 are contiguous in [n_theta][n_points]: beam i of the pair */
+    const int32_t* col = job.hit_col + (size_t)t0 * n;
+    const int32_t* row = job.hit_row + (size_t)t0 * n;
+    const uint32_t hmask = (uint32_t)hash_size - 1u;
+
+    constexpr int kAhead = 5;
+    constexpr int kBinBlock = kBinjBlock;      /* shadows the per-slice kernel's block size below */
+    int rv[kAhead], cv[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+        const int i = u * kBinBlock + tid;
+        rv[u] = cv[u] = 0;
+        if (i < n2) {
+            rv[u] = row[i];
+            cv[u] = col[i];
+        }
+    }
+    for (int i = tid; i < 2 * ntp; i += kBinBlock)
+        rowmask[i] = 0ull;
+    for (int i = tid; i < hash_size; i += kBinBlock) {
+        hval[i] = 0ull;
+        hkey[i] = 0u;
+    }
+    for (int i = tid; i < ntp; i += kBinBlock)
+        cnt[i] = 0u;
+    if (tid == 0)
+        list_n = 0u;
+    __syncthreads();
+
+    const int r_max = uni(job.rows) - 1 - uni(job.y_lo);
+    const int c_max = uni(job.cols) - 1 - uni(job.x_lo);
+    bool band = false;
+    const int fs = uni(job.frame_shift);
+    const int x_hi = uni(job.x_hi), y_hi = uni(job.y_hi), x_lo = uni(job.x_lo), y_lo = uni(job.y_lo);
+    const int n_band = uni(job.n_band);
+    const int n_iter = (n2 + kBinBlock - 1) / kBinBlock;
+    auto in_band = [&](int u, int w, int span, int known_lo) {
+        if (u > 0 || u <= -span)
+            return false;
+        const int m = (-u) % w;
+        return m != 0 && w - 1 - m >= known_lo;
+    };
+    const int known_r0 = uni(job.known_r0), known_c0 = uni(job.known_c0);
+    for (int it0 = 0; it0 < n_iter; it0 += kAhead) {
+        if (it0) {
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int i = (it0 + u) * kBinBlock + tid;
+                if (i < n2) {
+                    rv[u] = row[i];
+                    cv[u] = col[i];
+                }
+            }
+        }
+        uint32_t key[kAhead], slot[kAhead];
+        unsigned long long beams[kAhead];
+        bool pend[kAhead], first[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            key[u] = 0xffffffffu;
+            slot[u] = 0;
+            beams[u] = 0ull;
+            pend[u] = first[u] = false;
+            if (it0 + u >= n_iter)
+                continue;
+            const int i = (it0 + u) * kBinBlock + tid;
+            const int r = rv[u], c = cv[u];
+            const int rr = r + y_hi + fs, cc = c + x_hi;
+            const bool valid = i < n2 && rr >= fs && r <= r_max && cc >= 0 && c <= c_max;
+            const uint32_t sl = i >= n ? 1u : 0u;              /* which slice of the pair */
+            bool odd = false;
+            uint32_t cmp = 0xffffffffu;
+            if (valid) {
+                const uint32_t tile = ((uint32_t)rr / kTile) * (uint32_t)tiles_x + (uint32_t)cc / kTile;
+                const uint32_t rb = (uint32_t)rr % kTile, cb = (uint32_t)cc % kTile;
+                key[u] = ((tile << 12) | ((rb >> 1) << 6) | cb) + 1u;
+                odd = (rb & 1u) != 0;
+                cmp = key[u] | (sl << 31);                     /* a run never spans the two slices */
+            }
+            const uint32_t prev = (uint32_t)__shfl_up((int)cmp, 1, 64);
+            const bool head = valid && (lane == 0 || cmp != prev);
+            const unsigned long long hm = __ballot(head), vm = __ballot(valid), om = __ballot(odd);
+            const unsigned long long above = (hm | ~vm) & ~((2ull << lane) - 1ull);
+            const int e = above ? __builtin_ctzll(above) : 64;
+            const unsigned long long run = (e == 64 ? ~0ull : (1ull << e) - 1ull) & ~((1ull << lane) - 1ull);
+            const uint32_t co = (uint32_t)__popcll(run & om), ce = (uint32_t)__popcll(run) - co;
+            beams[u] = (unsigned long long)(ce | (co << 16)) << (32u * sl);
+            slot[u] = (key[u] * 2654435761u) >> 12 & hmask;
+            pend[u] = head;
+            const bool near_low_edge = i < n2 && (r + y_lo <= 0 || c + x_lo <= 0);
+            if (__any(near_low_edge)) {
+                if (near_low_edge)
+                    for (int b = 0; b < n_band; ++b) {
+                        const int w = job.band_win[b];
+                        if (in_band(r + y_lo, w, job.band_ny[b] * w, known_r0) ||
+                            in_band(c + x_lo, w, job.band_nx[b] * w, known_c0))
+                            band = true;
+                    }
+            }
+        }
+        bool any = true;
+        while (any) {
+            uint32_t old[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u)
+                old[u] = pend[u] ? atomicCAS(&hkey[slot[u]], 0u, key[u]) : 0u;
+            any = false;
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u)
+                if (pend[u]) {
+                    if (old[u] == 0u || old[u] == key[u]) {
+                        first[u] = old[u] == 0u;
+                        atomicAdd(&hval[slot[u]], beams[u]);
+                        pend[u] = false;
+                    } else {
+                        slot[u] = (slot[u] + 1u) & hmask;
+                        any = true;
+                    }
+                }
+            any = __any(any);
+        }
+        /* the lanes that claimed an empty slot append it to the list */
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const unsigned long long fm = __ballot(first[u]);
+            if (fm) {                           /* wave-uniform */
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&list_n, (uint32_t)__popcll(fm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (first[u])
+                    list[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint16_t)slot[u];
+            }
+        }
+    }
+    if (band)
+        atomicOr(job.flags, kFlagBandTouch);
+    __syncthreads();
+
+    const uint32_t max_mult = (uint32_t)uni(job.max_mult);
+    auto chunks = [&](uint32_t b) { return (b + max_mult - 1u) / max_mult; };
+    const int n_cells = uni((int)list_n);
+    auto cell_slot = [&](int e) { return (uint32_t)list[e]; };
+    auto entries_of = [&](unsigned long long hv) {
+        const uint32_t lo = (uint32_t)hv, hi = (uint32_t)(hv >> 32);
+        return max(max(chunks(lo & 0xffffu), chunks(lo >> 16)), max(chunks(hi & 0xffffu), chunks(hi >> 16)));
+    };
+
+    /* Pass B: entries per tile, bounding boxes */
+    for (int e = tid; e < n_cells; e += kBinBlock) {
+        const uint32_t sl = cell_slot(e);
+        const uint32_t k1 = hkey[sl] - 1u;
+        const unsigned long long hv = hval[sl];
+        const int tile = (int)(k1 >> 12);
+        const uint32_t rk = (k1 >> 6) & 63u, cbk = k1 & 63u;
+        const bool any_even = (hv & 0x0000ffff0000ffffull) != 0, any_odd = (hv & 0xffff0000ffff0000ull) != 0;
+        const uint32_t rlo = 2u * rk + (any_even ? 0u : 1u), rhi = 2u * rk + (any_odd ? 1u : 0u);
+        atomicAdd(&cnt[tile], entries_of(hv));
+        atomicOr(&rowmask[tile], (1ull << rlo) | (1ull << rhi));
+        atomicOr(&colmask[tile], 1ull << cbk);
+    }
+    __syncthreads();
+
+    /* exclusive scan of entry counts and of the records per tile */
+    const int chunk = (ntile + kBinBlock - 1) / kBinBlock;
+    const int lo = tid * chunk, hi = min(lo + chunk, ntile);
+    uint32_t csum = 0, ne = 0, excl_cnt, excl_rec;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t c = cnt[i];
+        csum += c;
+        ne += (c + kPbMax - 1) / kPbMax;
+    }
+    {
+        uint32_t a = csum, b = ne;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
+            if (lane >= d) {
+                a += ua;
+                b += ub;
+            }
+        }
+        __shared__ uint32_t wtot[2][kBinBlock / 64];
+        if (lane == 63) {
+            wtot[0][tid >> 6] = a;
+            wtot[1][tid >> 6] = b;
+        }
+        __syncthreads();
+        uint32_t ba = 0, bb2 = 0;
+        for (int w = 0; w < (tid >> 6); ++w) {
+            ba += wtot[0][w];
+            bb2 += wtot[1][w];
+        }
+        excl_cnt = ba + a - csum;
+        excl_rec = bb2 + b - ne;
+        if (tid == kBinBlock - 1)
+            job.n_tiles[p] = (int32_t)(bb2 + b);
+    }
+    {
+        uint32_t off = excl_cnt, slot_rec = excl_rec;
+        TileRec* recs = job.tiles + (size_t)p * job.max_tiles;
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t c = cnt[i];
+            if (!c)
+                continue;
+            const unsigned long long rm = rowmask[i], cm = colmask[i];
+            const int rlo = __builtin_ctzll(rm), rhi = 63 - __builtin_clzll(rm);
+            const int clo = __builtin_ctzll(cm), chi = 63 - __builtin_clzll(cm);
+            const int rmin = rlo & ~1;
+            for (uint32_t done = 0; done < c; done += kPbMax) {
+                TileRec rec;
+                rec.r0 = (i / tiles_x) * kTile - y_hi - fs + rmin;
+                rec.c0 = (i % tiles_x) * kTile - x_hi + clo;
+                rec.start = off + done;
+                rec.count = min(c - done, (uint32_t)kPbMax);
+                rec.h = rhi - rmin + 1;
+                rec.w = chi - clo + 1;
+                rec.pad[0] = 0;
+                rec.pad[1] = (int)(((uint32_t)i << 4) | (done / kPbMax));
+                recs[slot_rec++] = rec;
+            }
+            cnt[i] = off;                          /* the tile's cursor */
+            off += c;
+        }
+    }
+    __syncthreads();
+
+    /* Pass C: the entries */
+    uint32_t* out = job.sorted_pb + (size_t)p * 2 * n;
+    uint32_t* out_rc = job.sorted_rc ? job.sorted_rc + (size_t)p * 2 * n : nullptr;
+    const uint32_t lstride = (uint32_t)uni(job.lstride);
+    for (int e = tid; e < n_cells; e += kBinBlock) {
+        const uint32_t sl = cell_slot(e);
+        const uint32_t k1 = hkey[sl] - 1u;
+        const unsigned long long hv = hval[sl];
+        const int tile = (int)(k1 >> 12);
+        const uint32_t rmin = (uint32_t)__builtin_ctzll(rowmask[tile]) & ~1u;
+        const uint32_t rb = (((k1 >> 6) & 63u) << 1) - rmin;        /* even */
+        const uint32_t cb = (k1 & 63u) - (uint32_t)__builtin_ctzll(colmask[tile]);
+        uint32_t b0 = (uint32_t)hv & 0xffffu, b1 = ((uint32_t)hv >> 16), b2 = (uint32_t)(hv >> 32) & 0xffffu,
+                 b3 = (uint32_t)(hv >> 48);
+        const uint32_t total = entries_of(hv);
+        uint32_t pos = atomicAdd(&cnt[tile], total);
+        for (uint32_t k = 0; k < total; ++k, ++pos) {
+            const uint32_t m0 = min(b0, max_mult), m1 = min(b1, max_mult), m2 = min(b2, max_mult),
+                           m3 = min(b3, max_mult);
+            b0 -= m0;
+            b1 -= m1;
+            b2 -= m2;
+            b3 -= m3;
+            const uint32_t mults = (m0 << 16) | (m1 << 20) | (m2 << 24) | (m3 << 28);
+            out[pos] = mults | ((rb >> 1) * lstride + cb);
+            if (out_rc)
+                out_rc[pos] = mults | (rb << 7) | cb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBinjBlock, 4) void k_binj_batch(const BinJob* jobs)
+{
+    k_binj_body(jobs[blockIdx.y]);
+}
+
+/* ------------------------------------------------------------------ K1, joint */
+
+/* The multiply-adds of one entry: four blocks of R -- (even row, slice 0), (even row, slice 1),
+ * (odd row, slice 0), (odd row, slice 1) -- each skipped by a scalar branch when its 4-bit beam
+ * count in the entry word is zero (s_bfe_u32 sets SCC = result != 0). v[0 .. R] are the cells
+ * of the lane's R candidate rows and the one below (even rows use v[r], odd rows v[r + 1]).
+ * ONE asm statement: the compiler sees straight-line code (the reads of the next entry are in
+ * flight across it), adds no hazard padding between the blocks and cannot reorder them. */
+#define CSM_JMAD(a, v) "v_mad_u32_u24 %[" #a "], %[" #v "], %[m], %[" #a "]\n\t"
+template <int R>
+__device__ __forceinline__ void joint_mads(uint32_t w, const uint32_t (&v)[R + 2], uint32_t (&a)[R], uint32_t (&b)[R])
+{
+    static_assert(R == 6 || R == 8, "rows per lane");
+    uint32_t m;
+    if constexpr (R == 8) {
+        asm("s_bfe_u32 %[m], %[w], 0x40010\n\t"
+            "s_cbranch_scc0 1f\n\t"
+            CSM_JMAD(a0, v0) CSM_JMAD(a1, v1) CSM_JMAD(a2, v2) CSM_JMAD(a3, v3)
+            CSM_JMAD(a4, v4) CSM_JMAD(a5, v5) CSM_JMAD(a6, v6) CSM_JMAD(a7, v7)
+            "1:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40018\n\t"
+            "s_cbranch_scc0 2f\n\t"
+            CSM_JMAD(b0, v0) CSM_JMAD(b1, v1) CSM_JMAD(b2, v2) CSM_JMAD(b3, v3)
+            CSM_JMAD(b4, v4) CSM_JMAD(b5, v5) CSM_JMAD(b6, v6) CSM_JMAD(b7, v7)
+            "2:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40014\n\t"
+            "s_cbranch_scc0 3f\n\t"
+            CSM_JMAD(a0, v1) CSM_JMAD(a1, v2) CSM_JMAD(a2, v3) CSM_JMAD(a3, v4)
+            CSM_JMAD(a4, v5) CSM_JMAD(a5, v6) CSM_JMAD(a6, v7) CSM_JMAD(a7, v8)
+            "3:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x4001c\n\t"
+            "s_cbranch_scc0 4f\n\t"
+            CSM_JMAD(b0, v1) CSM_JMAD(b1, v2) CSM_JMAD(b2, v3) CSM_JMAD(b3, v4)
+            CSM_JMAD(b4, v5) CSM_JMAD(b5, v6) CSM_JMAD(b6, v7) CSM_JMAD(b7, v8)
+            "4:"
+            : [m] "=&s"(m), [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]),
+              [a5] "+v"(a[5]), [a6] "+v"(a[6]), [a7] "+v"(a[7]), [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]),
+              [b3] "+v"(b[3]), [b4] "+v"(b[4]), [b5] "+v"(b[5]), [b6] "+v"(b[6]), [b7] "+v"(b[7])
+            : [w] "s"(w), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]),
+              [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]), [v8] "v"(v[8])
+            : "scc");
+    } else {
+        asm("s_bfe_u32 %[m], %[w], 0x40010\n\t"
+            "s_cbranch_scc0 1f\n\t"
+            CSM_JMAD(a0, v0) CSM_JMAD(a1, v1) CSM_JMAD(a2, v2) CSM_JMAD(a3, v3) CSM_JMAD(a4, v4) CSM_JMAD(a5, v5)
+            "1:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40018\n\t"
+            "s_cbranch_scc0 2f\n\t"
+            CSM_JMAD(b0, v0) CSM_JMAD(b1, v1) CSM_JMAD(b2, v2) CSM_JMAD(b3, v3) CSM_JMAD(b4, v4) CSM_JMAD(b5, v5)
+            "2:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40014\n\t"
+            "s_cbranch_scc0 3f\n\t"
+            CSM_JMAD(a0, v1) CSM_JMAD(a1, v2) CSM_JMAD(a2, v3) CSM_JMAD(a3, v4) CSM_JMAD(a4, v5) CSM_JMAD(a5, v6)
+            "3:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x4001c\n\t"
+            "s_cbranch_scc0 4f\n\t"
+            CSM_JMAD(b0, v1) CSM_JMAD(b1, v2) CSM_JMAD(b2, v3) CSM_JMAD(b3, v4) CSM_JMAD(b4, v5) CSM_JMAD(b5, v6)
+            "4:"
+            : [m] "=&s"(m), [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]),
+              [a5] "+v"(a[5]), [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [b3] "+v"(b[3]), [b4] "+v"(b[4]),
+              [b5] "+v"(b[5])
+            : [w] "s"(w), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]),
+              [v5] "v"(v[5]), [v6] "v"(v[6])
+            : "scc");
+    }
+}
+#undef CSM_JMAD
+
+/* The entries of one record from the staged window into the accumulators of both slices.
+ * Rules of the hand-issued reads as in pairs_gather (csm_kernels.hip): a read reaches its
+ * lds_wait inside one basic block; groups of four entries, two entries' reads in flight. */
+template <int LS, int R>
+__device__ __forceinline__ void joint_gather(uint32_t lane_addr, const uint32_t* lpb, int lane, int cnt,
+                                             uint32_t (&acc0)[R], uint32_t (&S0)[R], uint32_t (&K0)[R],
+                                             FlushState& fs0, uint32_t (&acc1)[R], uint32_t (&S1)[R],
+                                             uint32_t (&K1)[R], FlushState& fs1)
+{
+    constexpr int kRowBytes = LS * 8;
+    constexpr int NQ = R / 2 + 1;
+    auto flush = [](uint32_t (&acc)[R], uint32_t (&S)[R], uint32_t (&K)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S[r] += acc[r];
+            K[r] += acc[r] >> 23;
+            acc[r] = 0;
+        }
+    };
+    auto issue = [&](uint32_t w, unsigned long long (&q)[NQ]) {
+        const uint32_t addr = lane_addr + ((w & 0x3fffu) << 3);
+        lds_read_b64<0 * kRowBytes>(addr, q[0]);
+        lds_read_b64<1 * kRowBytes>(addr, q[1]);
+        lds_read_b64<2 * kRowBytes>(addr, q[2]);
+        lds_read_b64<3 * kRowBytes>(addr, q[3]);
+        if (R >= 8)
+            lds_read_b64<4 * kRowBytes>(addr, q[4]);
+    };
+    auto mads = [&](uint32_t w, const unsigned long long (&q)[NQ]) {
+        uint32_t v[R + 2];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            v[2 * i] = (uint32_t)q[i];
+            v[2 * i + 1] = (uint32_t)(q[i] >> 32);
+        }
+        joint_mads<R>(w, v, acc0, acc1);
+    };
+    uint32_t pb_cur;
+    unsigned long long flags0, flags1;
+    auto flags_of = [&](int b, int real, FlushState& fs) {
+        const int c1 = fs.cum + wave_prefix_sum(b), c0 = c1 - b;
+        const bool cross = ((uint32_t)c1 * 683u) >> 16 != ((uint32_t)c0 * 683u) >> 16;      /* floor(c / 96) */
+        const unsigned long long heavy = __builtin_amdgcn_ballot_w64(b > 8);
+        const unsigned long long f = __builtin_amdgcn_ballot_w64(cross) | heavy | heavy << 1 | heavy << 2 |
+                                     heavy << 3 | heavy << 4 | (fs.carry ? 0xfull : 0ull);
+        fs.carry = (heavy >> max(0, real - 4)) != 0;        /* among the last four real entries */
+        fs.cum = __builtin_amdgcn_readlane(c1, 63) % 96;
+        return f;
+    };
+    auto load_chunk = [&](int j0) {
+        pb_cur = lpb[j0 + lane];
+        const bool real = j0 + lane < cnt;
+        const int b0 = real ? (int)(((pb_cur >> 16) & 15u) + ((pb_cur >> 20) & 15u)) : 0;
+        const int b1 = real ? (int)(((pb_cur >> 24) & 15u) + (pb_cur >> 28)) : 0;
+        const int nreal = min(64, cnt - j0);
+        flags0 = flags_of(b0, nreal, fs0);
+        flags1 = flags_of(b1, nreal, fs1);
+    };
+    int j = 0;
+    load_chunk(0);
+    while (j < cnt) {
+        const int stop = min(cnt, (j | 63) + 1);
+        for (; j + 4 <= stop; j += 4) {
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+            const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
+            const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
+            const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
+            if ((flags0 >> (j & 63)) & 0xfull)
+                flush(acc0, S0, K0);
+            if ((flags1 >> (j & 63)) & 0xfull)
+                flush(acc1, S1, K1);
+            unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ];
+            issue(o0, qa);
+            issue(o1, qb);
+            lds_wait<NQ, NQ>(qa);
+            mads(o0, qa);
+            issue(o2, qc);
+            lds_wait<NQ, NQ>(qb);
+            mads(o1, qb);
+            issue(o3, qd);
+            lds_wait<NQ, NQ>(qc);
+            mads(o2, qc);
+            lds_wait<0, NQ>(qd);
+            mads(o3, qd);
+        }
+        for (; j < stop; ++j) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+            if ((flags0 >> (j & 63)) & 1ull)
+                flush(acc0, S0, K0);
+            if ((flags1 >> (j & 63)) & 1ull)
+                flush(acc1, S1, K1);
+            unsigned long long qa[NQ];
+            issue(o, qa);
+            lds_wait<0, NQ>(qa);
+            mads(o, qa);
+        }
+        if ((j & 63) == 0 && j < cnt)
+            load_chunk(j);
+    }
+}
+
+/* One workgroup = (pair of theta slices, block of cbx x groups * R candidate offsets). Lane
+ * <-> candidate mapping, window staging (LDS-DMA from the pair-row copy of the level), the
+ * epilogue and the row-block split (BlockBase) as in score_body_pairs2; ONE record list. */
+template <int LS, int R>
+__device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map,
+                                                 int bid_x, int bid_y, BlockBase bb)
+{
+    static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
+    const int t0 = 2 * bid_y, t1 = t0 + 1;
+    const int n_theta = __builtin_amdgcn_readfirstlane(job.n_theta);
+    if (t0 >= n_theta)
+        return;
+    const bool two = t1 < n_theta;
+    const int tid = threadIdx.x;
+    const int ncbx = (job.nx + cbx - 1) / cbx;
+    const int bx = bid_x % ncbx, by = bid_x / ncbx;
+    const int cby = groups * R;
+    const int row0 = bb.row_base + by * cby;
+    if (row0 >= job.ny)
+        return;
+    const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
+
+    int dxi = tid % cbx, g = tid / cbx;
+    bool idle = false;
+    if (lane_map) {
+        const uint32_t m = lane_map[tid];
+        dxi = (int)(m & 255u);
+        g = (int)((m >> 8) & 127u);
+        idle = (m >> 15) != 0;
+    }
+    const bool lane_on = !idle && g < groups;
+    const int x0 = job.x_lo + bx * cbx;
+    const int y0 = job.y_lo + row0;
+    constexpr int kRowBytes = LS * 8;
+    const int prows_full = (kTile + cby) / 2 + 1;
+    const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
+    uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
+    uint32_t* lpb = sm_cells + max_pieces * 256;
+    const int tb = lane_on || (idle && g < groups && dxi < cbx) ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
+                                                       row0 + g * R < job.ny) != 0;
+
+    uint32_t S0[R], K0[R], acc0[R], S1[R], K1[R], acc1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        S0[r] = K0[r] = acc0[r] = S1[r] = K1[r] = acc1[r] = 0;
+    FlushState fs0 = { 0, 0 }, fs1 = { 0, 0 };
+
+    const int ntiles = __builtin_amdgcn_readfirstlane(job.in_s ? 0 : job.n_tiles[bid_y]);
+    const TileRec* recs = job.tiles + (size_t)bid_y * job.max_tiles;
+    const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)bid_y * 2 * job.n_points;
+    const size_t xg_pitch = (size_t)job.xg_pitch;
+    const size_t xg_row_bytes = xg_pitch * 8;
+    const char* xg = reinterpret_cast<const char*>(job.xg);
+    const int pad = job.xg_pad;
+
+    constexpr int kMaxP = ((((kTile + kPairMaxCby) / 2 + 1) * kRowBytes + 1023) / 1024 + 7) / 8;
+    uint32_t goff[kMaxP];
+#pragma unroll
+    for (int k = 0; k < kMaxP; ++k) {
+        const uint32_t ob = (uint32_t)(wave + 8 * k) * 1024u + (uint32_t)lane * 16u;
+        const uint32_t prow = ob / (uint32_t)kRowBytes, cb = ob - prow * (uint32_t)kRowBytes;
+        goff[k] = prow * (uint32_t)xg_row_bytes + cb;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    TileRec rec;
+    if (ntiles > 0)
+        rec = recs[0];
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int c00 = __builtin_amdgcn_readfirstlane(rec.c0) + x0;
+        const int gr0 = __builtin_amdgcn_readfirstlane(rec.r0) + y0;          /* even */
+        const int a = c00 & 1;
+        const int cnt = __builtin_amdgcn_readfirstlane((int)rec.count);
+        const int start = __builtin_amdgcn_readfirstlane((int)rec.start);
+        const int nprows = (__builtin_amdgcn_readfirstlane(rec.h) + cby) >> 1;
+        const int npieces = (nprows * kRowBytes + 1023) >> 10;
+        const char* src = xg + ((size_t)((gr0 + pad) >> 1) * xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
+        if (ti + 1 < ntiles)
+            rec = recs[ti + 1];
+        __syncthreads();                                 /* previous tile consumed */
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int k = 0; k < kMaxP; ++k) {
+            const int pc = wave + 8 * k;
+            if (pc < npieces)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(src + goff[k]), (lds_ptr)(sm_cells + pc * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < kPbMax / 64 / 8; ++e) {
+            const int pe = wave + 8 * e;
+            if (pe * 64 < cnt)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(pbs + start + pe * 64 + lane),
+                                                 (lds_ptr)(lpb + pe * 64), 4, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
+        if (wave_live)
+            joint_gather<LS, R>(lane_addr, lpb, lane, cnt, acc0, S0, K0, fs0, acc1, S1, K1, fs1);
+    }
+    pairs_finish<R>(acc0, S0, K0);
+    pairs_finish<R>(acc1, S1, K1);
+    score_epilogue<R>(job, S0, K0, t0, bx, 1, cbx, row0, g, dxi, lane_on, qflags, bid_x + bb.cb_base, bb.ncb);
+    if (two) {
+        __syncthreads();                                 /* the epilogue's reduction arrays */
+        score_epilogue<R>(job, S1, K1, t1, bx, 1, cbx, row0, g, dxi, lane_on, qflags, bid_x + bb.cb_base, bb.ncb);
+    }
+}
+
+/* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
+template <int LS, int R>
+__global__ __launch_bounds__(kBlock, 4) void k_score_joint_batch(const ScoreJob* jobs, int cbx, int groups,
+                                                                 const uint16_t* lane_map, int xcd_map, BlockBase bb)
+{
+    int bx, by, bz;
+    xcd_block(xcd_map, bx, by, bz);
+    score_body_joint<LS, R>(jobs[bz], cbx, groups, lane_map, bx, by, bb);
+}
+
+} /* namespace csm */
+
+/* ------------------------------------------------------------------ host launchers */
+
+namespace {
+
+/* Dynamic LDS above 64 KB needs the function attribute; process-wide, only ever raised. */
+hipError_t grant_lds(int device, const void* fn, size_t bytes)
+{
+    if (bytes <= 64 * 1024)
+        return hipSuccess;
+    static std::mutex guard;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    std::lock_guard<std::mutex> lock(guard);
+    size_t& have = granted[{ device, fn }];
+    if (bytes > have) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        have = bytes;
+    }
+    return hipSuccess;
+}
+
+template <int LS, int R>
+hipError_t launch_joint(const csm::JointLaunch& L)
+{
+    auto kernel = csm::k_score_joint_batch<LS, R>;
+    const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(kernel), L.lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(kernel, L.grid, dim3(csm::kBlock), L.lds_bytes, L.stream, L.jobs_dev, L.cbx, L.groups,
+                       L.lane_map, L.xcd_map, csm::BlockBase{ L.row_base, L.cb_base, L.ncb });
+    return hipGetLastError();
+}
+
+} /* namespace */
+
+namespace csm {
+
+size_t binj_lds_bytes(int tiles, int n_points, int hash_size)
+{
+    const size_t ntp = (size_t)((tiles + 1) & ~1);
+    return 20 * ntp + 12 * (size_t)hash_size + 2 * (size_t)(2 * n_points) + 16;
+}
+
+int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, int n_pairs_max, int n_jobs,
+                      size_t lds_bytes)
+{
+    const hipError_t e = grant_lds(device, reinterpret_cast<const void*>(k_binj_batch), lds_bytes);
+    if (e != hipSuccess)
+        return (int)e;
+    hipLaunchKernelGGL(k_binj_batch, dim3(n_pairs_max, n_jobs), dim3(kBinjBlock), lds_bytes, stream, jobs_dev);
+    return (int)hipGetLastError();
+}
+
+#define JOINT_CASE(LS)                                                                 \
+    if (L.ls == LS && L.R == 8)                                                        \
+        return (int)launch_joint<LS, 8>(L);                                            \
+    if (L.ls == LS && L.R == 6)                                                        \
+        return (int)launch_joint<LS, 6>(L);
+
+int launch_joint_batch(const JointLaunch& L)
+{
+#ifdef CSM_FAST_BUILD
+    JOINT_CASE(150)
+#else
+    JOINT_CASE(86) JOINT_CASE(98) JOINT_CASE(118) JOINT_CASE(124) JOINT_CASE(130) JOINT_CASE(150)
+    JOINT_CASE(156) JOINT_CASE(162) JOINT_CASE(182)
+#endif
+    return -1;      /* no instantiation for this row pitch */
+}
+
+} /* namespace csm */
