@@ -616,7 +616,7 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
     scans_per_step = n_chunks * WINDOWS_PER_LAUNCH
     wl = make_workload(rank, n_distinct)
     rx, ry, rt, L = wl["params"]
-    ctx = api.Context(dev_index)
+    ctx = api.Context(dev_index, tuning_off=args.tuning_off)
     # a non-default torch stream: csm_set_stream(NULL) would mean "the context's
     # own stream", and the collectives below must be ordered against the scoring
     ctx.set_stream(stream.cuda_stream)
@@ -679,6 +679,9 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
         dt = time.perf_counter() - t0
         ctx.enable_kernel_timing(False)
         fine_ms, fine_n = ctx.kernel_time("score_fine")
+        bound_ms, bound_n = ctx.kernel_time("score_bound")      # the packed-fp32 bound pass of the fine level
+        fine_ms += bound_ms
+        blocks_scored, blocks_skipped = ctx.bound_pass_stats()
         ctx.lib.csm_enable_kernel_timing(ctx._ctx, 1)
         ctx.reset_kernel_timing()
         step()
@@ -746,6 +749,11 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
                 "parallelism": "independent replicas per GPU, all-gather of 48-B best records" if world > 1
                                else "single GPU",
                 "poses_found": n_found,
+                "fine_level": ("packed-fp32 bound pass over every candidate (relative error < (beams + 3) 2^-24, "
+                               "proven) + exact integer kernel on the %.2f %% of candidate blocks within that bound of "
+                               "the window's maximum" % (100.0 * blocks_scored / max(1, blocks_scored + blocks_skipped)))
+                              if blocks_skipped else "exact integer kernel on every candidate block",
+                "bound_pass_us_per_launch": bound_ms / max(1, bound_n) * 1e3,
                 "verified": verified,
                 "verified_note": "records of the last timed step compared, after the timed region, with the CPU "
                                  "oracle's literal sweep (best x, y, theta and the f64 score at tolerance 0)",
@@ -801,6 +809,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tuning-off", type=int, default=0,
+                    help="csm_config.tuning_off bits (CSM_TUNE_*: A/B runs of single launch optimisations)")
     ap.add_argument("--verify", type=int, default=24,
                     help="records of the last timed step compared with the CPU oracle after the timed region "
                          "(configs[1] workload; 0 = none)")

@@ -71,6 +71,8 @@ typedef struct csm_ctx csm_ctx;
 #define CSM_TUNE_NO_TILE_SPLIT      32u   /* small single windows are never tile-split */
 #define CSM_TUNE_MAP_HOST_PROJECTION 64u  /* map building: hit points computed on the host */
 #define CSM_TUNE_NO_JOINT          128u   /* batch fine kernel: per-slice entry lists (round-2 form) */
+#define CSM_TUNE_NO_BOUND_PASS     256u   /* no packed-fp32 bound pass: the exact integer kernel scores
+                                             every candidate block */
 
 typedef struct {
     int32_t  device_id;          /* HIP device ordinal */
@@ -279,14 +281,22 @@ int  csm_score_window_dev(csm_ctx* ctx, uint64_t map_id, const csm_window* w,
 int  csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids,
                            const csm_window* windows, const int32_t* const* hit_col_dev,
                            const int32_t* const* hit_row_dev, csm_result* out_dev);
-/* The same launch chain with a dump of every candidate's integer sums for parity
- * tests of the batched kernels: dump_s_dev[i] / dump_k_dev[i] are device pointers
- * (or NULL, per window or for the whole array) to S [n_theta][nx][ny] uint32 and
- * K [..] uint16 of window i (nx = ceil((2*win_x+1)/L)*L). */
+/* The same launch chain with dumps for parity tests of the batched kernels, each a
+ * device pointer per window or NULL (per window or for a whole array):
+ * dump_s_dev[i] / dump_k_dev[i]: every candidate's integer sums S [n_theta][nx][ny]
+ * uint32 and K [..] uint16 (nx = ceil((2*win_x+1)/L)*L); a window with either set is
+ * scored by the exact kernel on every candidate block. dump_f_dev[i]: every
+ * candidate's fp32 order key from the bound pass, [n_theta][nx][ny] float (written
+ * only when the bound pass runs for the window's group). */
 int  csm_score_windows_dump_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids,
                                 const csm_window* windows, const int32_t* const* hit_col_dev,
                                 const int32_t* const* hit_row_dev, csm_result* out_dev,
-                                uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev);
+                                uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev,
+                                float* const* dump_f_dev);
+/* Two-pass fine level of the batch entries: candidate blocks the exact
+ * integer kernel scored / skipped after the packed-fp32 bound pass since the last call
+ * (synchronises the context's stream; resets the counters). */
+int  csm_bound_pass_stats(csm_ctx* ctx, uint64_t* blocks_scored, uint64_t* blocks_skipped);
 /* Synchronises, reads *out_dev and, when it carries a key tie or an edge-band
  * flag, runs the exact device paths (f64 tie replay / literal sequential
  * sweep) for the window just scored with csm_score_window_dev(); no-op

@@ -36,6 +36,7 @@ class Config(C.Structure):
 # csm_config.tuning_off bits (include/csm_hip.h)
 TUNE_NO_LANE_MAP, TUNE_NO_XCD_MAP, TUNE_NO_PAIR_TAIL, TUNE_NO_TWO_SLICES = 1, 2, 4, 8
 TUNE_NO_THETA_MAJOR, TUNE_NO_TILE_SPLIT, TUNE_MAP_HOST_PROJECTION, TUNE_NO_JOINT = 16, 32, 64, 128
+TUNE_NO_BOUND_PASS = 256
 GROUP_FORCE_RCCL = 1
 
 
@@ -175,7 +176,8 @@ SIGNATURES = {
     "csm_score_windows_dev": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "csm_score_windows_dump_dev": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "csm_bound_pass_stats": (C.c_int, [_ctx, _P(C.c_uint64), _P(C.c_uint64)]),
     "csm_resolve_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "csm_score_window_dump": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,

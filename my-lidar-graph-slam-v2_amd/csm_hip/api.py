@@ -293,15 +293,23 @@ class Context:
         self._check(self.lib.csm_score_windows_dev(self._ctx, n, ids, wins, cols, rows,
                                                    C.c_void_p(out_ptr)))
 
-    def score_windows_dump_dev(self, prepared, out_ptr, dump_s_ptrs, dump_k_ptrs):
-        """score_windows_dev() that also writes every candidate's integer sums of the
-        windows whose dump pointers (device, 0 = none) are given: S uint32 and K uint16,
-        [n_theta][nx][ny] each."""
+    def score_windows_dump_dev(self, prepared, out_ptr, dump_s_ptrs=None, dump_k_ptrs=None, dump_f_ptrs=None):
+        """score_windows_dev() that also writes, for the windows whose device pointers
+        (0 = none) are given, every candidate's integer sums (S uint32, K uint16) and / or
+        its fp32 key from the bound pass, [n_theta][nx][ny] each."""
         n, ids, wins, cols, rows = prepared
-        ds = (C.c_void_p * n)(*[p or None for p in dump_s_ptrs])
-        dk = (C.c_void_p * n)(*[p or None for p in dump_k_ptrs])
-        self._check(self.lib.csm_score_windows_dump_dev(self._ctx, n, ids, wins, cols, rows,
-                                                        C.c_void_p(out_ptr), ds, dk))
+
+        def arr(ptrs):
+            return (C.c_void_p * n)(*[p or None for p in ptrs]) if ptrs is not None else None
+        self._check(self.lib.csm_score_windows_dump_dev(self._ctx, n, ids, wins, cols, rows, C.c_void_p(out_ptr),
+                                                        arr(dump_s_ptrs), arr(dump_k_ptrs), arr(dump_f_ptrs)))
+
+    def bound_pass_stats(self):
+        """(candidate blocks the exact kernel scored, blocks it skipped after the fp32 bound
+        pass) since the last call."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.csm_bound_pass_stats(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def correlative_match(self, map_id, geom, angles, ranges, rel_pose, init_pose,
                           range_x, range_y, range_theta, low_resolution,

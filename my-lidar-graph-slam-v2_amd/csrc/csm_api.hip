@@ -72,6 +72,11 @@ struct DeviceGrid {
     size_t xg_cap = 0;
     int xg_pad = 0, xg_pitch = 0;
     bool xg_stale = true;
+    /* the same layout holding float(499 v + 32268 (v != 0)) per cell: source of the fp32 bound
+     * pass of the joint fine level (k_expand_pairs_f); follows xg */
+    float* xgf = nullptr;
+    size_t xgf_cap = 0;
+    bool xgf_valid = false;
     /* block-allocation bitmap for the cost function's ProbabilityOr(.., 0.5): one byte per
      * block; the caller's (csm_set_block_allocation) or derived from the cells */
     uint8_t* alloc = nullptr;
@@ -102,6 +107,7 @@ struct Tuning {
     bool pair_tail = true;     /* a window's last row block as an R = 6 launch */
     bool two_slices = true;    /* batch fine kernel takes two theta slices per workgroup */
     bool joint = true;         /* ... on joint entry lists of the two slices (k_binj / k_score_joint_batch) */
+    bool bound_pass = true;    /* ... preceded by the packed-fp32 bound pass; the exact kernel skips blocks that cannot win */
     bool tile_split = true;    /* small single windows: tile list split over blockIdx.z */
     bool map_host_projection = false;   /* map building: hit points on the host */
     int  theta_major = -1;     /* -1: by launch size */
@@ -120,7 +126,7 @@ struct csm_ctx {
     double* lut_dev = nullptr;
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
-    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out;
+    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out, b_abest, bound_stats;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     std::map<std::array<int, 4>, uint16_t*> lane_maps;   /* lane_map_for(): (cbx, groups, R, LS) -> device table */
     void* pin = nullptr;          /* pinned staging of csm_upload_grid */
@@ -205,7 +211,8 @@ struct ScopedTimer {
     const char* name;
     ScopedTimer(csm_ctx* c, const char* n) : ctx(c), name(n)
     {
-        if (!ctx->timing || (ctx->timing == 2 && std::strcmp(n, "score_fine") != 0))
+        if (!ctx->timing ||
+            (ctx->timing == 2 && std::strcmp(n, "score_fine") != 0 && std::strcmp(n, "score_bound") != 0))
             return;
         auto get = [&]() {
             hipEvent_t e = nullptr;
@@ -382,6 +389,7 @@ struct PassPlan {
     bool pairs = false;       /* pair-row fine kernel (k_score_pairs): lstride = slots per pair row */
     int lists = 1;            /* entry lists in LDS: 2 = the batch kernel that takes two slices per workgroup */
     bool joint = false;       /* ... on joint entries of the two slices (one list; csm_joint_kernels.hip) */
+    bool fp32 = false;        /* this launch is the packed-fp32 bound pass of the joint kernel */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -948,6 +956,7 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
         L.row_base = bb.row_base;
         L.cb_base = bb.cb_base;
         L.ncb = bb.ncb;
+        L.fp32 = pp.fp32 ? 1 : 0;
         const int e = csm::launch_joint_batch(L);
         if (e < 0)
             return fail(ctx, CSM_EINVAL, "internal: no joint kernel for LS %d R %d", pp.lstride, pp.R);
@@ -1021,6 +1030,11 @@ void free_levels(DeviceGrid& g, bool keep_base)
         g.xg = nullptr;
         g.xg_cap = 0;
         g.xg_stale = true;
+        if (g.xgf)
+            (void)hipFree(g.xgf);
+        g.xgf = nullptr;
+        g.xgf_cap = 0;
+        g.xgf_valid = false;
         if (g.alloc)
             (void)hipFree(g.alloc);
         g.alloc = nullptr;
@@ -1172,6 +1186,35 @@ int ensure_xgrid(csm_ctx* ctx, DeviceGrid& g, int need_pad)
     g.xg_pad = pad;
     g.xg_pitch = xp;
     g.xg_stale = false;
+    g.xgf_valid = false;
+    return CSM_OK;
+}
+
+/* The fp32 key copy in the layout of the (up-to-date) pair-row copy. */
+int ensure_xgrid_f(csm_ctx* ctx, DeviceGrid& g)
+{
+    if (g.xgf && g.xgf_valid)
+        return CSM_OK;
+    if (!g.xg || g.xg_stale)
+        return fail(ctx, CSM_EINVAL, "internal: pair-row copy missing");
+    const int prows = (g.rows + 2 * g.xg_pad + 1) / 2 + 1;
+    const size_t bytes = (size_t)prows * g.xg_pitch * 8;
+    if (bytes > g.xgf_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (g.xgf)
+            (void)hipFree(g.xgf);
+        g.xgf = nullptr;
+        g.xgf_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&g.xgf), bytes) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+        g.xgf_cap = bytes;
+    }
+    ScopedTimer tm(ctx, "expand");
+    const int e = csm::launch_expand_pairs_f(ctx->stream, g.levels[0].cells, g.rows, g.cols, g.pitch, g.xgf, prows,
+                                             g.xg_pitch, g.xg_pad);
+    if (e != 0)
+        return fail(ctx, CSM_EIO, "k_expand_pairs_f launch failed: %s", hipGetErrorString((hipError_t)e));
+    g.xgf_valid = true;
     return CSM_OK;
 }
 
@@ -1600,6 +1643,7 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.pair_tail = !(off & CSM_TUNE_NO_PAIR_TAIL);
         t.two_slices = !(off & CSM_TUNE_NO_TWO_SLICES);
         t.joint = !(off & CSM_TUNE_NO_JOINT);
+        t.bound_pass = !(off & CSM_TUNE_NO_BOUND_PASS);
         t.tile_split = !(off & CSM_TUNE_NO_TILE_SPLIT);
         t.map_host_projection = (off & CSM_TUNE_MAP_HOST_PROJECTION) != 0;
         if (off & CSM_TUNE_NO_THETA_MAJOR)
@@ -1617,6 +1661,7 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.pair_tail = env_int("CSM_PAIR_TAIL", t.pair_tail) != 0;
         t.two_slices = env_int("CSM_PAIR_SLICES", t.two_slices ? 2 : 1) != 1;
         t.joint = env_int("CSM_JOINT", t.joint) != 0;
+        t.bound_pass = env_int("CSM_BOUND_PASS", t.bound_pass) != 0;
         t.theta_major = env_int("CSM_THETA_MAJOR", t.theta_major);
         t.fine_slices = env_int("CSM_FINE_SLICES", 0);
         t.force_r = env_int("CSM_FORCE_R", 0);
@@ -1658,7 +1703,7 @@ int csm_destroy(csm_ctx* ctx)
     DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
-                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out,
+                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
                        &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs, &ctx->box_jobs,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
@@ -2383,6 +2428,7 @@ struct ResidentBatch {
     csm_result* out_dev;                  /* [n] device */
     uint32_t* const* dump_s = nullptr;    /* optional [n] device pointers (any may be null): every candidate's */
     uint16_t* const* dump_k = nullptr;    /* integer sums, [n_theta][nx][ny] (parity tests) */
+    float* const* dump_f = nullptr;       /* optional: every candidate's fp32 key of the bound pass */
 };
 
 /* One group of queries that share (nx, ny): the whole device pipeline. */
@@ -2476,12 +2522,21 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     const bool joint = ctx->tune.joint && lp[0].pairs && lp[0].lists == 2 && lp[0].weighted &&
                        binj_lds <= 78 * 1024;      /* two binning workgroups per CU */
     lp[0].joint = joint;
+    /* The packed-fp32 bound pass in front of the exact kernel: only where the arg-max is over ALL
+     * candidates of the window -- the correlative sweep with a known-rate threshold that the coarse
+     * level passes whenever a fine candidate scores at all (min_known <= 1; a touched edge band
+     * switches the skipping off per query on the device). Branch and bound tests every leaf's own
+     * known count: exact kernel only. */
+    bool bound_pass = joint && ctx->tune.bound_pass && !spec.bnb;
+    for (int k = 0; k < nq && bound_pass; ++k)
+        bound_pass = (resident ? resident->windows[idx[k]].min_known
+                               : csm_host_min_known(pp[k].n, spec.known_thr)) <= 1;
     for (int k = 0; k < nq; ++k) {
         BatchPrep& p = pp[k];
         /* lists and records per slice, or per pair of slices (2 n entries each) */
         const int units = joint ? (p.n_theta + 1) / 2 : p.n_theta;
         const int per_unit = joint ? 2 * p.n : p.n;
-        p.max_tiles = std::min(per_unit, p.tiles_x * p.tiles_y) + per_unit / kPbMax + 1;
+        p.max_tiles = std::min(per_unit, p.tiles_x * p.tiles_y) + per_unit / (joint ? kJRec : kPbMax) + 1;
         bin_lds = std::max(bin_lds, bin_lds_bytes(p.tiles_x * p.tiles_y, p.n));
         p.hit_off = hit_total;
         p.tile_off = tile_total;
@@ -2573,6 +2628,15 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     if ((rc = ensure(ctx, ctx->b_ntiles, theta_total * 4))) return rc;
     if ((rc = ensure(ctx, ctx->b_lvl, lvl_total * 8 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->b_best, best_total * sizeof(BlockBest)))) return rc;
+    if (bound_pass) {
+        if (!ctx->bound_stats.p) {
+            if ((rc = ensure(ctx, ctx->bound_stats, 64))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->bound_stats.p, 0, 64, ctx->stream));
+        }
+        if ((rc = ensure(ctx, ctx->b_abest, best_total * sizeof(float)))) return rc;
+        for (int k = 0; k < nq; ++k)
+            if ((rc = ensure_xgrid_f(ctx, *pp[k].grid))) return rc;
+    }
     if ((rc = ensure(ctx, ctx->b_out, (size_t)nq * (sizeof(csm_result) + 4)))) return rc;
     const size_t jobs_bytes = (size_t)nq * (sizeof(ProjJob) + sizeof(BinJob) + sizeof(FinalJob) +
                                             (size_t)(H + 1) * sizeof(ScoreJob) + (size_t)H * sizeof(ZeroJob));
@@ -2727,6 +2791,18 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         F.ny = ny;
         F.stride = 1;
         F.block_best = d_best + p.best_off;
+        if (bound_pass) {
+            F.xgf = g.xgf;
+            F.approx_best = reinterpret_cast<float*>(ctx->b_abest.p) + p.best_off;
+            /* |fp32 key - key| <= (n + 2) 2^-24 * key for a sum of n non-negative terms (one rounding
+             * per fused multiply-add, one for each cell's float, one for joining the two accumulator
+             * sets), n <= beams. A candidate that reaches the winner's exact key has an fp32 key of at
+             * least max_fp32 * (1 - 3 (n + 3) 2^-24); the kernel compares with 4 (n + 3) 2^-24. */
+            F.approx_slack = 4.0f * (float)(p.n + 3) * 5.9604645e-08f;
+            F.bound_stats = reinterpret_cast<uint32_t*>(ctx->bound_stats.p);
+            if (resident && resident->dump_f)
+                F.dump_f = resident->dump_f[idx[k]];
+        }
         if (resident && resident->dump_s)
             F.dump_s = resident->dump_s[idx[k]];
         if (resident && resident->dump_k)
@@ -2861,6 +2937,13 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         ScopedTimer tm(ctx, "score_coarse");
         if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[h]), nq, lp[h],
                                      n_theta_max, n_slices, all_exit && nq >= 16 ? 4 : 0)))
+            return rc;
+    }
+    if (bound_pass) {
+        PassPlan fp = lp[0];
+        fp.fp32 = true;
+        ScopedTimer tm(ctx, "score_bound");
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, fp, n_theta_max, 1)))
             return rc;
     }
     {
@@ -3250,12 +3333,13 @@ int csm_score_windows_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, cons
                           csm_result* out_dev)
 {
     return csm_score_windows_dump_dev(ctx, n, map_ids, windows, hit_col_dev, hit_row_dev, out_dev, nullptr,
-                                      nullptr);
+                                      nullptr, nullptr);
 }
 
 int csm_score_windows_dump_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids, const csm_window* windows,
                                const int32_t* const* hit_col_dev, const int32_t* const* hit_row_dev,
-                               csm_result* out_dev, uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev)
+                               csm_result* out_dev, uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev,
+                               float* const* dump_f_dev)
 {
     if (!ctx || n < 1 || !map_ids || !windows || !hit_col_dev || !hit_row_dev || !out_dev)
         return fail(ctx, CSM_EINVAL, "csm_score_windows_dev: bad arguments");
@@ -3286,7 +3370,7 @@ int csm_score_windows_dump_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids,
         const int nx = ceil_div(2 * w.win_x + 1, L) * L, ny = ceil_div(2 * w.win_y + 1, L) * L;
         groups[{ nx, ny, L, w.merge_mode }].push_back(i);
     }
-    ResidentBatch resident { windows, hit_col_dev, hit_row_dev, out_dev, dump_s_dev, dump_k_dev };
+    ResidentBatch resident { windows, hit_col_dev, hit_row_dev, out_dev, dump_s_dev, dump_k_dev, dump_f_dev };
     /* drop the tables of earlier calls whose launch chains have completed */
     while (!ctx->resident_hold.empty()) {
         const bool full = ctx->resident_hold.size() >= 256;
@@ -3409,6 +3493,22 @@ int csm_build_pyramids(csm_ctx* ctx, const uint64_t* map_ids, int32_t n_maps, co
 }
 
 /* ---- measurement hooks ---- */
+
+int csm_bound_pass_stats(csm_ctx* ctx, uint64_t* blocks_scored, uint64_t* blocks_skipped)
+{
+    if (!ctx)
+        return CSM_EINVAL;
+    uint32_t h[2] = { 0, 0 };
+    if (ctx->bound_stats.p) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->bound_stats.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->bound_stats.p, 0, 8, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (blocks_scored) *blocks_scored = h[0];
+    if (blocks_skipped) *blocks_skipped = h[1];
+    return CSM_OK;
+}
 
 int csm_enable_kernel_timing(csm_ctx* ctx, int32_t enable)
 {

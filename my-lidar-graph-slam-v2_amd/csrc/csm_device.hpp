@@ -12,6 +12,8 @@ constexpr int kMaxRegionRows = 128;        /* LDS region rows of a stride-1 job 
 constexpr int kMaxRegionRowsStrided = 128; /* ... of a strided (coarser level) job */
 constexpr int kPairMaxCby = 56;  /* candidate rows per workgroup of the pair-row fine kernel */
 constexpr int kPbMax = 1024;       /* entries per TileRec: k_bin splits fuller tiles */
+constexpr int kJRec = 256;         /* entries per TileRec of a joint list (k_binj): the record's float beam counts
+                                      (16 B per entry) live in LDS during the fp32 bound pass */
 constexpr int kMaxMult = 15;       /* beams merged into one (cell, multiplicity) entry */
 constexpr int kMaxPoints = 10240;  /* beams per scan: k_bin's hash table (16384 slots, load <= 2/3, 128 KB)
                                       and cell list must fit the CU's 160 KB of LDS */
@@ -155,6 +157,18 @@ struct ScoreJob {
     int32_t skip_unless_band;
     int32_t elig_only_if_band;
     EligLevel elig[kMaxElig];
+    /* fp32 bound pass of the joint fine level (csm_joint_kernels.hip): every candidate's key
+     * 32268 K + 499 S evaluated in packed fp32 from `xgf`, a copy of the level in the layout of
+     * `xg` holding float(499 v + 32268 (v != 0)) per cell. The pass writes the greatest value of
+     * each (slice, candidate block) to approx_best [n_theta][blocks]; the exact integer kernel
+     * then skips the blocks that provably cannot hold the winner (approx_slack: relative margin
+     * 4 (N + 3) 2^-24 covering both passes' rounding). Null / 0: no bound pass. */
+    const float* xgf;
+    float* approx_best;
+    float* dump_f;             /* optional [n_theta][nx][ny]: every candidate's fp32 key (tests) */
+    float approx_slack;
+    int32_t pad1;
+    uint32_t* bound_stats;     /* optional [2]: blocks the exact kernel scored / skipped after the bound pass */
 };
 
 /* Reduce block results, replay the winner in f64, write the result record. */

@@ -23,6 +23,7 @@ struct JointLaunch {
     const uint16_t* lane_map;
     int xcd_map;
     int row_base, cb_base, ncb; /* BlockBase: where this launch sits among the window's row blocks */
+    int fp32;                   /* 1: the packed-fp32 bound pass (k_score_jointf_batch) */
 };
 
 /* LDS bytes of k_binj for a frame of `tiles` endpoint tiles, n_points beams per slice and a
@@ -35,6 +36,10 @@ int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, in
                       size_t lds_bytes);
 
 int launch_joint_batch(const JointLaunch& launch);
+
+/* xgf = the level's fp32 key copy in the layout of its pair-row copy (k_expand_pairs_f) */
+int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, int cols, int pitch, float* xgf,
+                          int xg_prows, int xg_pitch, int pad);
 
 } /* namespace csm */
 #endif

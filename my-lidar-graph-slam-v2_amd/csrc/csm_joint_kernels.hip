@@ -25,6 +25,7 @@
 
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 #include "csm_score_common.hpp"
@@ -242,7 +243,7 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
     for (int i = lo; i < hi; ++i) {
         const uint32_t c = cnt[i];
         csum += c;
-        ne += (c + kPbMax - 1) / kPbMax;
+        ne += (c + kJRec - 1) / kJRec;
     }
     {
         uint32_t a = csum, b = ne;
@@ -281,16 +282,16 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
             const int rlo = __builtin_ctzll(rm), rhi = 63 - __builtin_clzll(rm);
             const int clo = __builtin_ctzll(cm), chi = 63 - __builtin_clzll(cm);
             const int rmin = rlo & ~1;
-            for (uint32_t done = 0; done < c; done += kPbMax) {
+            for (uint32_t done = 0; done < c; done += kJRec) {
                 TileRec rec;
                 rec.r0 = (i / tiles_x) * kTile - y_hi - fs + rmin;
                 rec.c0 = (i % tiles_x) * kTile - x_hi + clo;
                 rec.start = off + done;
-                rec.count = min(c - done, (uint32_t)kPbMax);
+                rec.count = min(c - done, (uint32_t)kJRec);
                 rec.h = rhi - rmin + 1;
                 rec.w = chi - clo + 1;
                 rec.pad[0] = 0;
-                rec.pad[1] = (int)(((uint32_t)i << 4) | (done / kPbMax));
+                rec.pad[1] = (int)(((uint32_t)i << 4) | (done / kJRec));
                 recs[slot_rec++] = rec;
             }
             cnt[i] = off;                          /* the tile's cursor */
@@ -526,6 +527,51 @@ __device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, i
     if (row0 >= job.ny)
         return;
     const uint32_t qflags = job.elig_only_if_band ? *job.flags : 0u;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    /* After the fp32 bound pass: a block whose greatest fp32 key lies below the window's greatest
+     * by more than the two passes' rounding can hold neither the winner nor a candidate that ties
+     * with it (approx_slack, csm_api.hip), so it reports "no candidate" and leaves. Not when a
+     * beam can reach the negative edge band (then eligibility against the coarser level decides,
+     * which the bound pass ignores) and not when every candidate's sums are wanted. */
+    if (job.approx_best && !job.dump_s && !job.dump_k && !(qflags & kFlagBandTouch)) {
+        __shared__ float wmax[kBlock / 64];
+        const float* ab = job.approx_best;
+        const int total = n_theta * bb.ncb;
+        float m = 0.f;
+        for (int i = tid; i < total; i += kBlock)
+            m = fmaxf(m, ab[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            m = fmaxf(m, __shfl_xor(m, d, 64));
+        if (lane == 0)
+            wmax[wave] = m;
+        __syncthreads();
+        m = wmax[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w)
+            m = fmaxf(m, wmax[w]);
+        const int cbg = bid_x + bb.cb_base;
+        const float mine = fmaxf(ab[(size_t)t0 * bb.ncb + cbg], two ? ab[(size_t)t1 * bb.ncb + cbg] : 0.f);
+        const bool skip = mine < m * (1.0f - job.approx_slack);
+        if (tid == 0 && job.bound_stats)
+            atomicAdd(job.bound_stats + (skip ? 1 : 0), 1u);
+        if (skip) {
+            if (tid == 0 && job.block_best) {
+                BlockBest none;
+                none.key = 0;
+                none.rank = ~0ull;
+                none.count = 0;
+                none.pad = 0;
+                job.block_best[(size_t)t0 * bb.ncb + cbg] = none;
+                if (two)
+                    job.block_best[(size_t)t1 * bb.ncb + cbg] = none;
+            }
+            return;
+        }
+        __syncthreads();            /* wmax is reused by nobody, but keep the epilogue's arrays apart */
+    }
 
     int dxi = tid % cbx, g = tid / cbx;
     bool idle = false;
@@ -544,8 +590,6 @@ __device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, i
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb = sm_cells + max_pieces * 256;
     const int tb = lane_on || (idle && g < groups && dxi < cbx) ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
                                                        row0 + g * R < job.ny) != 0;
 
@@ -596,13 +640,10 @@ __device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, i
             if (pc < npieces)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(src + goff[k]), (lds_ptr)(sm_cells + pc * 256), 16, 0, 0);
         }
-#pragma unroll
-        for (int e = 0; e < kPbMax / 64 / 8; ++e) {
-            const int pe = wave + 8 * e;
-            if (pe * 64 < cnt)
-                __builtin_amdgcn_global_load_lds((glb_ptr)(pbs + start + pe * 64 + lane),
-                                                 (lds_ptr)(lpb + pe * 64), 4, 0, 0);
-        }
+        static_assert(kJRec / 64 <= 8, "one list piece per wave");
+        if (wave * 64 < cnt)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(pbs + start + wave * 64 + lane),
+                                             (lds_ptr)(lpb + wave * 64), 4, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -617,6 +658,342 @@ __device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, i
         __syncthreads();                                 /* the epilogue's reduction arrays */
         score_epilogue<R>(job, S1, K1, t1, bx, 1, cbx, row0, g, dxi, lane_on, qflags, bid_x + bb.cb_base, bb.ncb);
     }
+}
+
+/* ------------------------------------------------------------------ K1, joint, fp32 bound pass */
+/* The same gather in PACKED fp32: v_pk_fma_f32 does two multiply-adds per lane and instruction at
+ * the issue rate of v_mad_u32_u24 (tools/micro/pk_fma_bench.hip), and a ds_read_b64 of the
+ * pair-row layout delivers exactly the operand pair of two neighbouring candidate rows. What is
+ * summed is the candidate's ORDER KEY itself, 32268 K + 499 S = sum of beams * (499 v + 32268 (v != 0)),
+ * one float per cell (k_expand_pairs_f): no separate known count, no flushes. The sum is not exact
+ * (keys reach 2^35); every term is non-negative, so after n additions the relative error is below
+ * (n + 1) 2^-24. The pass therefore does not pick the winner: it writes the greatest value of every
+ * (slice, candidate block), and the exact integer kernel afterwards skips the blocks whose maximum
+ * lies more than the proven margin below the window's maximum (score_body_joint, `approx_best`).
+ *
+ * Row pairing. A lane's even candidate rows pair up with the row pairs of the LDS layout for a hit on
+ * an EVEN frame row: E[i] = (rows 2i, 2i + 1) += slot i. For a hit on the odd row the cells sit one
+ * row lower; instead of re-pairing registers the lane keeps a second accumulator set shifted by one
+ * row, O[i] = (rows 2i - 1, 2i) += slot i, i = 0 .. R/2 (rows -1 and R are never read). 4 + 5
+ * instructions per (slice, parity) for 8 candidate rows instead of 8. */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_expand_pairs_f(const uint16_t* __restrict__ cells, int rows, int cols,
+                                                       int pitch, float2* __restrict__ xgf, int xg_prows,
+                                                       int xg_pitch, int pad)
+{
+    const size_t total = (size_t)xg_prows * xg_pitch;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i / xg_pitch), c = (int)(i % xg_pitch) - pad;
+        const int r0 = 2 * k - pad;
+        uint32_t v0 = 0, v1 = 0;
+        if (c >= 0 && c < cols) {
+            if (r0 >= 0 && r0 < rows)
+                v0 = cells[(size_t)r0 * pitch + c];
+            if (r0 + 1 >= 0 && r0 + 1 < rows)
+                v1 = cells[(size_t)(r0 + 1) * pitch + c];
+        }
+        /* one rounding (values above 2^24): part of the bound pass's error budget */
+        xgf[i] = make_float2((float)(499u * v0 + 32268u * min(v0, 1u)), (float)(499u * v1 + 32268u * min(v1, 1u)));
+    }
+}
+
+/* The packed multiply-adds of one entry. fa = (float beams even row, odd row) of slice 0, fb of
+ * slice 1 (from the record's float table in LDS); zero counts are skipped by scalar branches on the
+ * integer counts in the entry word. */
+#define CSM_JFMA_E(acc, q, f) "v_pk_fma_f32 %[" #acc "], %[" #q "], %[" #f "], %[" #acc "] op_sel_hi:[1,0,1]\n\t"
+#define CSM_JFMA_O(acc, q, f) "v_pk_fma_f32 %[" #acc "], %[" #q "], %[" #f "], %[" #acc "] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+template <int R>
+__device__ __forceinline__ void joint_fmads(uint32_t w, const unsigned long long (&q)[R / 2 + 1], unsigned long long fa,
+                                            unsigned long long fb, f32x2 (&ea)[R / 2], f32x2 (&oa)[R / 2 + 1],
+                                            f32x2 (&eb)[R / 2], f32x2 (&ob)[R / 2 + 1])
+{
+    static_assert(R == 6 || R == 8, "rows per lane");
+    uint32_t m;
+    if constexpr (R == 8) {
+        asm("s_bfe_u32 %[m], %[w], 0x40010\n\t"
+            "s_cbranch_scc0 1f\n\t"
+            CSM_JFMA_E(ea0, q0, fa) CSM_JFMA_E(ea1, q1, fa) CSM_JFMA_E(ea2, q2, fa) CSM_JFMA_E(ea3, q3, fa)
+            "1:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40018\n\t"
+            "s_cbranch_scc0 2f\n\t"
+            CSM_JFMA_E(eb0, q0, fb) CSM_JFMA_E(eb1, q1, fb) CSM_JFMA_E(eb2, q2, fb) CSM_JFMA_E(eb3, q3, fb)
+            "2:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40014\n\t"
+            "s_cbranch_scc0 3f\n\t"
+            CSM_JFMA_O(oa0, q0, fa) CSM_JFMA_O(oa1, q1, fa) CSM_JFMA_O(oa2, q2, fa) CSM_JFMA_O(oa3, q3, fa)
+            CSM_JFMA_O(oa4, q4, fa)
+            "3:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x4001c\n\t"
+            "s_cbranch_scc0 4f\n\t"
+            CSM_JFMA_O(ob0, q0, fb) CSM_JFMA_O(ob1, q1, fb) CSM_JFMA_O(ob2, q2, fb) CSM_JFMA_O(ob3, q3, fb)
+            CSM_JFMA_O(ob4, q4, fb)
+            "4:"
+            : [m] "=&s"(m), [ea0] "+v"(ea[0]), [ea1] "+v"(ea[1]), [ea2] "+v"(ea[2]), [ea3] "+v"(ea[3]),
+              [oa0] "+v"(oa[0]), [oa1] "+v"(oa[1]), [oa2] "+v"(oa[2]), [oa3] "+v"(oa[3]), [oa4] "+v"(oa[4]),
+              [eb0] "+v"(eb[0]), [eb1] "+v"(eb[1]), [eb2] "+v"(eb[2]), [eb3] "+v"(eb[3]),
+              [ob0] "+v"(ob[0]), [ob1] "+v"(ob[1]), [ob2] "+v"(ob[2]), [ob3] "+v"(ob[3]), [ob4] "+v"(ob[4])
+            : [w] "s"(w), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [q4] "v"(q[4]),
+              [fa] "v"(fa), [fb] "v"(fb)
+            : "scc");
+    } else {
+        asm("s_bfe_u32 %[m], %[w], 0x40010\n\t"
+            "s_cbranch_scc0 1f\n\t"
+            CSM_JFMA_E(ea0, q0, fa) CSM_JFMA_E(ea1, q1, fa) CSM_JFMA_E(ea2, q2, fa)
+            "1:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40018\n\t"
+            "s_cbranch_scc0 2f\n\t"
+            CSM_JFMA_E(eb0, q0, fb) CSM_JFMA_E(eb1, q1, fb) CSM_JFMA_E(eb2, q2, fb)
+            "2:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x40014\n\t"
+            "s_cbranch_scc0 3f\n\t"
+            CSM_JFMA_O(oa0, q0, fa) CSM_JFMA_O(oa1, q1, fa) CSM_JFMA_O(oa2, q2, fa) CSM_JFMA_O(oa3, q3, fa)
+            "3:\n\t"
+            "s_bfe_u32 %[m], %[w], 0x4001c\n\t"
+            "s_cbranch_scc0 4f\n\t"
+            CSM_JFMA_O(ob0, q0, fb) CSM_JFMA_O(ob1, q1, fb) CSM_JFMA_O(ob2, q2, fb) CSM_JFMA_O(ob3, q3, fb)
+            "4:"
+            : [m] "=&s"(m), [ea0] "+v"(ea[0]), [ea1] "+v"(ea[1]), [ea2] "+v"(ea[2]),
+              [oa0] "+v"(oa[0]), [oa1] "+v"(oa[1]), [oa2] "+v"(oa[2]), [oa3] "+v"(oa[3]),
+              [eb0] "+v"(eb[0]), [eb1] "+v"(eb[1]), [eb2] "+v"(eb[2]),
+              [ob0] "+v"(ob[0]), [ob1] "+v"(ob[1]), [ob2] "+v"(ob[2]), [ob3] "+v"(ob[3])
+            : [w] "s"(w), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [fa] "v"(fa), [fb] "v"(fb)
+            : "scc");
+    }
+}
+#undef CSM_JFMA_E
+#undef CSM_JFMA_O
+
+/* ftab_addr: LDS byte address of the record's float table (16 B per entry: beams of even / odd
+ * row of slice 0, of slice 1); the two broadcast reads of an entry ride in the same lgkmcnt queue
+ * as its R/2 + 1 slot reads. */
+template <int LS, int R>
+__device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab_addr, const uint32_t* lpb, int lane,
+                                               int cnt, f32x2 (&ea)[R / 2], f32x2 (&oa)[R / 2 + 1],
+                                               f32x2 (&eb)[R / 2], f32x2 (&ob)[R / 2 + 1])
+{
+    constexpr int kRowBytes = LS * 8;
+    constexpr int NQ = R / 2 + 1;
+    constexpr int NP = NQ + 2;                      /* reads per entry */
+    auto issue = [&](uint32_t w, uint32_t faddr, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
+        const uint32_t addr = lane_addr + ((w & 0x3fffu) << 3);
+        lds_read_b64<0 * kRowBytes>(addr, q[0]);
+        lds_read_b64<1 * kRowBytes>(addr, q[1]);
+        lds_read_b64<2 * kRowBytes>(addr, q[2]);
+        lds_read_b64<3 * kRowBytes>(addr, q[3]);
+        if (R >= 8)
+            lds_read_b64<4 * kRowBytes>(addr, q[4]);
+        lds_read_b64<0>(faddr, f[0]);
+        lds_read_b64<8>(faddr, f[1]);
+    };
+    /* waits until all but the `LATER` youngest LDS reads have landed; ties every register the
+     * mads are about to read */
+    auto wait = [&](auto later, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
+        constexpr int LATER = decltype(later)::value;
+        if constexpr (R >= 8)
+            asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(f[0]), "+v"(f[1]) : "n"(LATER));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(f[0]), "+v"(f[1]) : "n"(LATER));
+    };
+    using later_t = std::integral_constant<int, NP>;
+    using now_t = std::integral_constant<int, 0>;
+    uint32_t pb_cur = lpb[lane];
+    int j = 0;
+    while (j < cnt) {
+        const int stop = min(cnt, (j | 63) + 1);
+        for (; j + 4 <= stop; j += 4) {
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+            const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
+            const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
+            const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
+            const uint32_t fbase = ftab_addr + (uint32_t)j * 16u;
+            unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ], fa[2], fb[2], fc[2], fd[2];
+            issue(o0, fbase, qa, fa);
+            issue(o1, fbase + 16u, qb, fb);
+            wait(later_t(), qa, fa);
+            joint_fmads<R>(o0, qa, fa[0], fa[1], ea, oa, eb, ob);
+            issue(o2, fbase + 32u, qc, fc);
+            wait(later_t(), qb, fb);
+            joint_fmads<R>(o1, qb, fb[0], fb[1], ea, oa, eb, ob);
+            issue(o3, fbase + 48u, qd, fd);
+            wait(later_t(), qc, fc);
+            joint_fmads<R>(o2, qc, fc[0], fc[1], ea, oa, eb, ob);
+            wait(now_t(), qd, fd);
+            joint_fmads<R>(o3, qd, fd[0], fd[1], ea, oa, eb, ob);
+        }
+        for (; j < stop; ++j) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
+            unsigned long long qa[NQ], fa[2];
+            issue(o, ftab_addr + (uint32_t)j * 16u, qa, fa);
+            wait(now_t(), qa, fa);
+            joint_fmads<R>(o, qa, fa[0], fa[1], ea, oa, eb, ob);
+        }
+        if ((j & 63) == 0 && j < cnt)
+            pb_cur = lpb[j + lane];
+    }
+}
+
+/* Workgroup = (pair of theta slices, candidate block), as score_body_joint; writes
+ * approx_best[t][block] = greatest fp32 key among the block's candidates of slice t (0 if none). */
+template <int LS, int R>
+__device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map,
+                                                  int bid_x, int bid_y, BlockBase bb)
+{
+    static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
+    __shared__ float red[2][kBlock / 64];
+    const int t0 = 2 * bid_y, t1 = t0 + 1;
+    const int n_theta = __builtin_amdgcn_readfirstlane(job.n_theta);
+    if (t0 >= n_theta || !job.approx_best)
+        return;
+    const bool two = t1 < n_theta;
+    const int tid = threadIdx.x;
+    const int ncbx = (job.nx + cbx - 1) / cbx;
+    const int bx = bid_x % ncbx, by = bid_x / ncbx;
+    const int cby = groups * R;
+    const int row0 = bb.row_base + by * cby;
+    if (row0 >= job.ny)
+        return;
+    int dxi = tid % cbx, g = tid / cbx;
+    bool idle = false;
+    if (lane_map) {
+        const uint32_t m = lane_map[tid];
+        dxi = (int)(m & 255u);
+        g = (int)((m >> 8) & 127u);
+        idle = (m >> 15) != 0;
+    }
+    const bool lane_on = !idle && g < groups;
+    const int x0 = job.x_lo + bx * cbx;
+    const int y0 = job.y_lo + row0;
+    constexpr int kRowBytes = LS * 8;
+    const int prows_full = (kTile + cby) / 2 + 1;
+    const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
+    uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
+    uint32_t* lpb = sm_cells + max_pieces * 256;                 /* [kJRec] entry words */
+    float4* ftab = reinterpret_cast<float4*>(lpb + kJRec);       /* [kJRec] float beam counts */
+    const int tb = lane_on || (idle && g < groups && dxi < cbx) ? (g * (R / 2)) * kRowBytes + 8 * dxi : 0;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool wave_live = __builtin_amdgcn_ballot_w64(lane_on && bx * cbx + dxi < job.nx &&
+                                                       row0 + g * R < job.ny) != 0;
+
+    f32x2 ea[R / 2], oa[R / 2 + 1], eb[R / 2], ob[R / 2 + 1];
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i)
+        ea[i] = eb[i] = f32x2{ 0.f, 0.f };
+#pragma unroll
+    for (int i = 0; i <= R / 2; ++i)
+        oa[i] = ob[i] = f32x2{ 0.f, 0.f };
+
+    const int ntiles = __builtin_amdgcn_readfirstlane(job.n_tiles[bid_y]);
+    const TileRec* recs = job.tiles + (size_t)bid_y * job.max_tiles;
+    const uint32_t* __restrict__ pbs = job.sorted_pb + (size_t)bid_y * 2 * job.n_points;
+    const size_t xg_pitch = (size_t)job.xg_pitch;
+    const size_t xg_row_bytes = xg_pitch * 8;
+    const char* xg = reinterpret_cast<const char*>(job.xgf);
+    const int pad = job.xg_pad;
+
+    constexpr int kMaxP = ((((kTile + kPairMaxCby) / 2 + 1) * kRowBytes + 1023) / 1024 + 7) / 8;
+    uint32_t goff[kMaxP];
+#pragma unroll
+    for (int k = 0; k < kMaxP; ++k) {
+        const uint32_t ob_ = (uint32_t)(wave + 8 * k) * 1024u + (uint32_t)lane * 16u;
+        const uint32_t prow = ob_ / (uint32_t)kRowBytes, cb = ob_ - prow * (uint32_t)kRowBytes;
+        goff[k] = prow * (uint32_t)xg_row_bytes + cb;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    TileRec rec;
+    if (ntiles > 0)
+        rec = recs[0];
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int c00 = __builtin_amdgcn_readfirstlane(rec.c0) + x0;
+        const int gr0 = __builtin_amdgcn_readfirstlane(rec.r0) + y0;
+        const int a = c00 & 1;
+        const int cnt = __builtin_amdgcn_readfirstlane((int)rec.count);
+        const int start = __builtin_amdgcn_readfirstlane((int)rec.start);
+        const int nprows = (__builtin_amdgcn_readfirstlane(rec.h) + cby) >> 1;
+        const int npieces = (nprows * kRowBytes + 1023) >> 10;
+        const char* src = xg + ((size_t)((gr0 + pad) >> 1) * xg_pitch + (size_t)((c00 & ~1) + pad)) * 8;
+        if (ti + 1 < ntiles)
+            rec = recs[ti + 1];
+        /* this thread's entry of the record, for the float table */
+        uint32_t my_w = 0;
+        if (tid < cnt)
+            my_w = pbs[start + tid];
+        __syncthreads();                                 /* previous tile consumed */
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int k = 0; k < kMaxP; ++k) {
+            const int pc = wave + 8 * k;
+            if (pc < npieces)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(src + goff[k]), (lds_ptr)(sm_cells + pc * 256), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        static_assert(kJRec <= kBlock, "one table entry per thread");
+        if (tid < cnt) {
+            lpb[tid] = my_w;
+            ftab[tid] = make_float4((float)((my_w >> 16) & 15u), (float)((my_w >> 20) & 15u),
+                                    (float)((my_w >> 24) & 15u), (float)(my_w >> 28));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
+        if (wave_live)
+            joint_gather_f<LS, R>(lane_addr, lds_address(ftab), lpb, lane, cnt, ea, oa, eb, ob);
+    }
+
+    /* this lane's candidates: column bx * cbx + dxi, rows row0 + g * R + r */
+    const int xi = bx * cbx + dxi;
+    float best0 = 0.f, best1 = 0.f;
+    float* const dump_f = job.dump_f;
+    if (lane_on && xi < job.nx) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yi = row0 + g * R + r;
+            if (yi >= job.ny)
+                continue;
+            const float w0 = (r & 1 ? ea[r / 2].y + oa[(r + 1) / 2].x : ea[r / 2].x + oa[r / 2].y);
+            const float w1 = (r & 1 ? eb[r / 2].y + ob[(r + 1) / 2].x : eb[r / 2].x + ob[r / 2].y);
+            best0 = fmaxf(best0, w0);
+            best1 = fmaxf(best1, w1);
+            if (dump_f) {
+                dump_f[((size_t)t0 * job.nx + xi) * job.ny + yi] = w0;
+                if (two)
+                    dump_f[((size_t)t1 * job.nx + xi) * job.ny + yi] = w1;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        best0 = fmaxf(best0, __shfl_xor(best0, m, 64));
+        best1 = fmaxf(best1, __shfl_xor(best1, m, 64));
+    }
+    if (lane == 0) {
+        red[0][wave] = best0;
+        red[1][wave] = best1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            best0 = fmaxf(best0, red[0][w]);
+            best1 = fmaxf(best1, red[1][w]);
+        }
+        const int cbg = bid_x + bb.cb_base;
+        job.approx_best[(size_t)t0 * bb.ncb + cbg] = best0;
+        if (two)
+            job.approx_best[(size_t)t1 * bb.ncb + cbg] = best1;
+    }
+}
+
+template <int LS, int R>
+__global__ __launch_bounds__(kBlock, 4) void k_score_jointf_batch(const ScoreJob* jobs, int cbx, int groups,
+                                                                  const uint16_t* lane_map, int xcd_map, BlockBase bb)
+{
+    int bx, by, bz;
+    xcd_block(xcd_map, bx, by, bz);
+    score_body_jointf<LS, R>(jobs[bz], cbx, groups, lane_map, bx, by, bb);
 }
 
 /* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
@@ -656,7 +1033,7 @@ hipError_t grant_lds(int device, const void* fn, size_t bytes)
 template <int LS, int R>
 hipError_t launch_joint(const csm::JointLaunch& L)
 {
-    auto kernel = csm::k_score_joint_batch<LS, R>;
+    auto kernel = L.fp32 ? csm::k_score_jointf_batch<LS, R> : csm::k_score_joint_batch<LS, R>;
     const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(kernel), L.lds_bytes);
     if (e != hipSuccess)
         return e;
@@ -690,6 +1067,16 @@ int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, in
         return (int)launch_joint<LS, 8>(L);                                            \
     if (L.ls == LS && L.R == 6)                                                        \
         return (int)launch_joint<LS, 6>(L);
+
+int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, int cols, int pitch, float* xgf,
+                          int xg_prows, int xg_pitch, int pad)
+{
+    const size_t total = (size_t)xg_prows * xg_pitch;
+    const int blocks = (int)(total + 255 < 4096 * 256 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_expand_pairs_f, dim3(blocks), dim3(256), 0, stream, cells, rows, cols, pitch,
+                       reinterpret_cast<float2*>(xgf), xg_prows, xg_pitch, pad);
+    return (int)hipGetLastError();
+}
 
 int launch_joint_batch(const JointLaunch& L)
 {

@@ -46,8 +46,8 @@ def headline(oracle):
     return wl, lits, dumps
 
 
-VARIANTS = [("default", 0), ("no_pair_tail", L.TUNE_NO_PAIR_TAIL), ("no_lane_map", L.TUNE_NO_LANE_MAP),
-            ("no_xcd_map", L.TUNE_NO_XCD_MAP), ("no_joint", L.TUNE_NO_JOINT),
+VARIANTS = [("default", 0), ("no_bound_pass", L.TUNE_NO_BOUND_PASS), ("no_pair_tail", L.TUNE_NO_PAIR_TAIL),
+            ("no_lane_map", L.TUNE_NO_LANE_MAP), ("no_xcd_map", L.TUNE_NO_XCD_MAP), ("no_joint", L.TUNE_NO_JOINT),
             ("one_slice", L.TUNE_NO_TWO_SLICES | L.TUNE_NO_JOINT),
             ("all_off", L.TUNE_NO_PAIR_TAIL | L.TUNE_NO_LANE_MAP | L.TUNE_NO_XCD_MAP | L.TUNE_NO_JOINT)]
 
@@ -77,8 +77,25 @@ def test_headline_batch_every_record_and_dumps(headline, name, tuning_off):
         keep += [torch.zeros(S.size, dtype=torch.int32, device=dev), torch.zeros(K.size, dtype=torch.int16, device=dev)]
         ds[k], dk[k] = keep[-2].data_ptr(), keep[-1].data_ptr()
     prepared = ctx.prepare_windows([1] * N_WIN, windows, cols, rows)
-    ctx.score_windows_dump_dev(prepared, out.data_ptr(), ds, dk)
+    # fp32 keys of the bound pass for the windows after the integer dumps (a window with integer
+    # dumps is scored exactly everywhere; these go through the skipping)
+    df = [0] * N_WIN
+    fkeep = []
+    for k in range(N_DUMP, 2 * N_DUMP):
+        wx, wy, wt = wl["scans"][k]["win"]
+        nx, ny = -(-(2 * wx + 1) // Lr) * Lr, -(-(2 * wy + 1) // Lr) * Lr
+        fkeep.append(torch.zeros((2 * wt + 1) * nx * ny, dtype=torch.float32, device=dev))
+        df[k] = fkeep[-1].data_ptr()
+    ctx.bound_pass_stats()
+    ctx.score_windows_dump_dev(prepared, out.data_ptr(), ds, dk, df)
     torch.cuda.synchronize(dev)
+    scored, skipped = ctx.bound_pass_stats()
+    bound_pass = not (tuning_off & (L.TUNE_NO_BOUND_PASS | L.TUNE_NO_JOINT | L.TUNE_NO_TWO_SLICES))
+    if bound_pass:
+        # the bound pass must leave the exact kernel a small share of the blocks
+        assert skipped > 20 * scored > 0, (scored, skipped)
+    else:
+        assert scored == skipped == 0
     rec = out.cpu().numpy().reshape(N_WIN, 48)
     n_flagged = 0
     for k in range(N_WIN):
@@ -102,4 +119,17 @@ def test_headline_batch_every_record_and_dumps(headline, name, tuning_off):
         K = keep[2 * N_WIN + 2 * k + 1].cpu().numpy().view(np.uint16).reshape(oK.shape)
         assert np.array_equal(S, oS), (name, k)
         assert np.array_equal(K, oK), (name, k)
+    if bound_pass:
+        # the bound itself: |fp32 key - exact key| <= (n + 3) 2^-24 * key for every candidate
+        from oracle import oracle as O
+        for j, k in enumerate(range(N_DUMP, 2 * N_DUMP)):
+            sc = wl["scans"][k]
+            case = dict(grid=wl["grid"], geom=wl["geom"], angles=sc["angles"], ranges=sc["ranges"],
+                        rel_pose=sc["rel_pose"], init_pose=sc["init_pose"])
+            _, oS, oK, _ = O.csm_closed_form(case, rx, ry, rt, Lr, dump=True)
+            key = 32268.0 * oK.astype(np.float64) + 499.0 * oS.astype(np.float64)
+            got = fkeep[j].cpu().numpy().astype(np.float64).reshape(key.shape)
+            err = np.abs(got - key)
+            assert np.all(err <= (bench.N_BEAMS + 3) * 2.0 ** -24 * key + 1e-9), (name, k, float(err.max()))
+            assert float(err.max()) > 0.0                     # it IS an approximation
     ctx.close()
