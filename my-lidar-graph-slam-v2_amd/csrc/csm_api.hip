@@ -126,7 +126,7 @@ struct csm_ctx {
     double* lut_dev = nullptr;
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
-    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out, b_abest, bound_stats;
+    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out, b_abest, bound_stats, b_items;
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     std::map<std::array<int, 4>, uint16_t*> lane_maps;   /* lane_map_for(): (cbx, groups, R, LS) -> device table */
     void* pin = nullptr;          /* pinned staging of csm_upload_grid */
@@ -528,6 +528,16 @@ bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two
                 p.lstride = ls;
                 break;
             }
+        /* R = 8 needs an odd pitch for that (no such LS) and takes the lane table instead; but where
+         * the window's last row block becomes an R = 6 launch (tail_split) BOTH launches read the
+         * pitch the entries were binned for: take the R = 6 launch's conflict-free pitch if close */
+        const int tail_ls_from = p.lstride;
+        if (R == 8 && tune.pair_tail)
+            for (int ls : kPairLS)
+                if (ls >= tail_ls_from && ls <= tail_ls_from + 8 && (3 * ls - p.cbx) % 32 == 0) {
+                    p.lstride = ls;
+                    break;
+                }
         int g = std::min(std::min(kBlock / p.cbx, ceil_div(ny, R)), kPairMaxCby / R);
         /* two workgroups per CU: at most 80 KB of LDS each INCLUDING the kernel's static
          * __shared__ arrays (a plan at exactly 80 KB of dynamic LDS ran one workgroup per
@@ -931,7 +941,23 @@ int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n
 }
 
 /* One launch of the pair kernels over row blocks [first block of `pp`'s numbering ...) of a batch. */
-int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& pp, dim3 grid, BlockBase bb)
+/* Work list of the exact joint kernel after the bound pass (k_bound_select): items of the main
+ * launch, items of the R = 6 tail launch, their counts, workgroups to share them. */
+struct JointList {
+    const uint32_t* items[2] = { nullptr, nullptr };
+    const uint32_t* counts = nullptr;       /* [2] */
+    int blocks = 0;
+};
+
+/* a window's last row block as an R = 6 launch of its own? (launch_score_batch) */
+bool tail_split(const csm_ctx* ctx, const PassPlan& pp)
+{
+    const int cby = pp.groups * pp.R, tail_rows = pp.ny - (pp.ncby - 1) * cby;
+    return pp.pairs && pp.R == 8 && pp.ncby >= 2 && tail_rows > 0 && tail_rows <= pp.groups * 6 && ctx->tune.pair_tail;
+}
+
+int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& pp, dim3 grid, BlockBase bb,
+                       const JointList* list = nullptr, int which = 0)
 {
     const size_t lds = pass_lds_bytes(pp);
     bool launched = false;
@@ -957,6 +983,11 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
         L.cb_base = bb.cb_base;
         L.ncb = bb.ncb;
         L.fp32 = pp.fp32 ? 1 : 0;
+        if (list && !pp.fp32) {
+            L.items = list->items[which];
+            L.item_count = list->counts + which;
+            L.list_blocks = list->blocks;
+        }
         const int e = csm::launch_joint_batch(L);
         if (e < 0)
             return fail(ctx, CSM_EINVAL, "internal: no joint kernel for LS %d R %d", pp.lstride, pp.R);
@@ -972,7 +1003,7 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
 }
 
 int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const PassPlan& pp,
-                       int n_theta_max, int n_slices, int theta_groups = 0)
+                       int n_theta_max, int n_slices, int theta_groups = 0, const JointList* list = nullptr)
 {
     /* theta_groups > 0: that many workgroups per (block, job) share the theta slices */
     const dim3 grid(pp.ncb(), (theta_groups > 0 && !pp.pairs) ? std::min(theta_groups, n_theta_max) : n_theta_max,
@@ -984,10 +1015,9 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
          * blocks of 48: the second block has 36). Where R = 6 covers it with the same lane
          * groups, that block is a launch of its own: three quarters of the reads and
          * multiply-adds per entry for half of the workgroups (CSM_TUNE_NO_PAIR_TAIL: one launch). */
-        const int cby = pp.groups * pp.R, tail_rows = pp.ny - (pp.ncby - 1) * cby;
-        const bool split = pp.R == 8 && pp.ncby >= 2 && tail_rows > 0 && tail_rows <= pp.groups * 6 && ctx->tune.pair_tail;
-        if (!split)
-            return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() });
+        const int cby = pp.groups * pp.R;
+        if (!tail_split(ctx, pp))
+            return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() }, list, 0);
         PassPlan tail = pp;
         tail.R = 6;
         /* The tail launch keeps the main launch's row pitch: k_bin wrote the entries' LDS offsets
@@ -996,11 +1026,11 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
          * every window on the wrong cells -- unnoticed because winners sit near the window's
          * centre; tests/test_gpu_headline.py (full S / K dumps of this launch shape) found it. */
         int rc = launch_pairs_batch(ctx, jobs_dev, pp, dim3(pp.ncbx * (pp.ncby - 1), grid.y, grid.z),
-                                    BlockBase{ 0, 0, pp.ncb() });
+                                    BlockBase{ 0, 0, pp.ncb() }, list, 0);
         if (rc)
             return rc;
         return launch_pairs_batch(ctx, jobs_dev, tail, dim3(pp.ncbx, grid.y, grid.z),
-                                  BlockBase{ (pp.ncby - 1) * cby, pp.ncbx * (pp.ncby - 1), pp.ncb() });
+                                  BlockBase{ (pp.ncby - 1) * cby, pp.ncbx * (pp.ncby - 1), pp.ncb() }, list, 1);
     }
     const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
     size_t lds = pass_lds_bytes(pp);
@@ -1703,7 +1733,7 @@ int csm_destroy(csm_ctx* ctx)
     DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
-                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats,
+                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats, &ctx->b_items,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
                        &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs, &ctx->box_jobs,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
@@ -2527,7 +2557,8 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
      * level passes whenever a fine candidate scores at all (min_known <= 1; a touched edge band
      * switches the skipping off per query on the device). Branch and bound tests every leaf's own
      * known count: exact kernel only. */
-    bool bound_pass = joint && ctx->tune.bound_pass && !spec.bnb;
+    bool bound_pass = joint && ctx->tune.bound_pass && !spec.bnb && nq < (1 << 14) && lp[0].ncb() <= 256 &&
+                      (n_theta_max + 1) / 2 <= 1024;       /* the work list's item format */
     for (int k = 0; k < nq && bound_pass; ++k)
         bound_pass = (resident ? resident->windows[idx[k]].min_known
                                : csm_host_min_known(pp[k].n, spec.known_thr)) <= 1;
@@ -2634,6 +2665,11 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
             HIP_TRY(ctx, hipMemsetAsync(ctx->bound_stats.p, 0, 64, ctx->stream));
         }
         if ((rc = ensure(ctx, ctx->b_abest, best_total * sizeof(float)))) return rc;
+        /* work lists of the exact kernel: [2 counts, pad][items 0][items 1], one item per (pair, block) */
+        size_t blocks_total = 0;
+        for (int k = 0; k < nq; ++k)
+            blocks_total += (size_t)((pp[k].n_theta + 1) / 2) * ncb;
+        if ((rc = ensure(ctx, ctx->b_items, 64 + 2 * blocks_total * 4))) return rc;
         for (int k = 0; k < nq; ++k)
             if ((rc = ensure_xgrid_f(ctx, *pp[k].grid))) return rc;
     }
@@ -2946,7 +2982,29 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, fp, n_theta_max, 1)))
             return rc;
     }
-    {
+    if (bound_pass) {
+        size_t blocks_total = 0;
+        for (int k = 0; k < nq; ++k)
+            blocks_total += (size_t)((pp[k].n_theta + 1) / 2) * ncb;
+        uint32_t* counts = reinterpret_cast<uint32_t*>(ctx->b_items.p);
+        uint32_t* items0 = counts + 16;
+        uint32_t* items1 = items0 + blocks_total;
+        JointList list;
+        list.items[0] = items0;
+        list.items[1] = items1;
+        list.counts = counts;
+        list.blocks = (int)std::min<size_t>(blocks_total, 2048);
+        ScopedTimer tm(ctx, "score_fine");
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, ctx->stream));
+        const int split_cb = tail_split(ctx, lp[0]) ? lp[0].ncbx * (lp[0].ncby - 1) : ncb;
+        const int e = csm::launch_bound_select(ctx->stream, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, ncb, split_cb,
+                                               items0, items1, counts, (uint32_t)blocks_total);
+        if (e != 0)
+            return fail(ctx, CSM_EIO, "k_bound_select launch failed: %s", hipGetErrorString((hipError_t)e));
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0], n_theta_max, 1, 0,
+                                     &list)))
+            return rc;
+    } else {
         ScopedTimer tm(ctx, "score_fine");
         if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0],
                                      n_theta_max, 1)))

@@ -24,6 +24,11 @@ struct JointLaunch {
     int xcd_map;
     int row_base, cb_base, ncb; /* BlockBase: where this launch sits among the window's row blocks */
     int fp32;                   /* 1: the packed-fp32 bound pass (k_score_jointf_batch) */
+    /* exact kernel over a work list (k_score_joint_list) instead of the grid: items / item_count
+     * as k_bound_select wrote them, list_blocks workgroups share them */
+    const uint32_t* items = nullptr;
+    const uint32_t* item_count = nullptr;
+    int list_blocks = 0;
 };
 
 /* LDS bytes of k_binj for a frame of `tiles` endpoint tiles, n_points beams per slice and a
@@ -36,6 +41,12 @@ int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, in
                       size_t lds_bytes);
 
 int launch_joint_batch(const JointLaunch& launch);
+
+/* After the bound pass (approx_best of every job written): clears every job's BlockBest records and
+ * lists the candidate blocks the exact kernel has to score: item = job << 18 | pair << 8 | block;
+ * blocks >= split_cb go to items1 (the row block of the R = 6 launch). counts[2] must be zero. */
+int launch_bound_select(hipStream_t stream, const ScoreJob* jobs_dev, int n_jobs, int ncb, int split_cb,
+                        uint32_t* items0, uint32_t* items1, uint32_t* counts, uint32_t cap);
 
 /* xgf = the level's fp32 key copy in the layout of its pair-row copy (k_expand_pairs_f) */
 int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, int cols, int pitch, float* xgf,

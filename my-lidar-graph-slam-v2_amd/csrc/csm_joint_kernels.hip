@@ -530,49 +530,6 @@ __device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, i
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    /* After the fp32 bound pass: a block whose greatest fp32 key lies below the window's greatest
-     * by more than the two passes' rounding can hold neither the winner nor a candidate that ties
-     * with it (approx_slack, csm_api.hip), so it reports "no candidate" and leaves. Not when a
-     * beam can reach the negative edge band (then eligibility against the coarser level decides,
-     * which the bound pass ignores) and not when every candidate's sums are wanted. */
-    if (job.approx_best && !job.dump_s && !job.dump_k && !(qflags & kFlagBandTouch)) {
-        __shared__ float wmax[kBlock / 64];
-        const float* ab = job.approx_best;
-        const int total = n_theta * bb.ncb;
-        float m = 0.f;
-        for (int i = tid; i < total; i += kBlock)
-            m = fmaxf(m, ab[i]);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1)
-            m = fmaxf(m, __shfl_xor(m, d, 64));
-        if (lane == 0)
-            wmax[wave] = m;
-        __syncthreads();
-        m = wmax[0];
-#pragma unroll
-        for (int w = 1; w < kBlock / 64; ++w)
-            m = fmaxf(m, wmax[w]);
-        const int cbg = bid_x + bb.cb_base;
-        const float mine = fmaxf(ab[(size_t)t0 * bb.ncb + cbg], two ? ab[(size_t)t1 * bb.ncb + cbg] : 0.f);
-        const bool skip = mine < m * (1.0f - job.approx_slack);
-        if (tid == 0 && job.bound_stats)
-            atomicAdd(job.bound_stats + (skip ? 1 : 0), 1u);
-        if (skip) {
-            if (tid == 0 && job.block_best) {
-                BlockBest none;
-                none.key = 0;
-                none.rank = ~0ull;
-                none.count = 0;
-                none.pad = 0;
-                job.block_best[(size_t)t0 * bb.ncb + cbg] = none;
-                if (two)
-                    job.block_best[(size_t)t1 * bb.ncb + cbg] = none;
-            }
-            return;
-        }
-        __syncthreads();            /* wmax is reused by nobody, but keep the epilogue's arrays apart */
-    }
-
     int dxi = tid % cbx, g = tid / cbx;
     bool idle = false;
     if (lane_map) {
@@ -1006,6 +963,84 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_joint_batch(const ScoreJob*
     score_body_joint<LS, R>(jobs[bz], cbx, groups, lane_map, bx, by, bb);
 }
 
+/* ---- after the bound pass: which candidate blocks the exact kernel still has to score ----
+ * One workgroup per job (window). M = the window's greatest fp32 key. A block (pair of slices,
+ * candidate block) whose own greatest key lies below M by more than the two passes' rounding
+ * (approx_slack) can hold neither the winner nor a candidate that ties with it: its BlockBest
+ * records stay "no candidate". Every other block becomes an item of the work list its launch
+ * reads (list 0: row blocks of the R = 8 launch, list 1: the window's last row block when that is
+ * an R = 6 launch). All blocks are kept when a beam can reach the negative edge band (eligibility
+ * against the coarser level then decides, which the bound pass ignores) or when every candidate's
+ * sums are wanted (dump_s / dump_k). item = job << 18 | pair << 8 | block. */
+__global__ __launch_bounds__(256) void k_bound_select(const ScoreJob* jobs, int ncb, int split_cb,
+                                                     uint32_t* items0, uint32_t* items1, uint32_t* counts,
+                                                     uint32_t cap)
+{
+    __shared__ float wmax[4];
+    const ScoreJob& job = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n_theta = job.n_theta;
+    const int total = n_theta * ncb;
+    const float* ab = job.approx_best;
+    float m = 0.f;
+    for (int i = tid; i < total; i += 256) {
+        m = fmaxf(m, ab[i]);
+        BlockBest none;
+        none.key = 0;
+        none.rank = ~0ull;
+        none.count = 0;
+        none.pad = 0;
+        job.block_best[i] = none;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((tid & 63) == 0)
+        wmax[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float thr = m * (1.0f - job.approx_slack);
+    const bool all = job.dump_s || job.dump_k || (job.elig_only_if_band && (*job.flags & kFlagBandTouch));
+    const int n_pairs = (n_theta + 1) / 2;
+    uint32_t kept = 0, dropped = 0;
+    for (int i = tid; i < n_pairs * ncb; i += 256) {
+        const int pr = i / ncb, cb = i - pr * ncb;
+        const int t0 = 2 * pr;
+        const float mine = fmaxf(ab[(size_t)t0 * ncb + cb], t0 + 1 < n_theta ? ab[(size_t)(t0 + 1) * ncb + cb] : 0.f);
+        if (all || mine >= thr) {
+            const int which = cb >= split_cb ? 1 : 0;
+            const uint32_t pos = atomicAdd(counts + which, 1u);
+            if (pos < cap)
+                (which ? items1 : items0)[pos] = ((uint32_t)blockIdx.x << 18) | ((uint32_t)pr << 8) | (uint32_t)cb;
+            ++kept;
+        } else {
+            ++dropped;
+        }
+    }
+    if (job.bound_stats) {
+        if (kept)
+            atomicAdd(job.bound_stats, kept);
+        if (dropped)
+            atomicAdd(job.bound_stats + 1, dropped);
+    }
+}
+
+/* The exact kernel over a work list: a fixed grid of workgroups takes the items i = blockIdx.x,
+ * blockIdx.x + gridDim.x, ... below *count (written by k_bound_select earlier on the stream). */
+template <int LS, int R>
+__global__ __launch_bounds__(kBlock, 4) void k_score_joint_list(const ScoreJob* jobs, int cbx, int groups,
+                                                                const uint16_t* lane_map, BlockBase bb,
+                                                                const uint32_t* items, const uint32_t* count)
+{
+    const uint32_t n = __builtin_amdgcn_readfirstlane((int)*count);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[i]);
+        score_body_joint<LS, R>(jobs[it >> 18], cbx, groups, lane_map, (int)(it & 255u) - bb.cb_base,
+                                (int)((it >> 8) & 1023u), bb);
+        __syncthreads();
+    }
+}
+
 } /* namespace csm */
 
 /* ------------------------------------------------------------------ host launchers */
@@ -1033,6 +1068,16 @@ hipError_t grant_lds(int device, const void* fn, size_t bytes)
 template <int LS, int R>
 hipError_t launch_joint(const csm::JointLaunch& L)
 {
+    if (L.items) {
+        auto list_kernel = csm::k_score_joint_list<LS, R>;
+        const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(list_kernel), L.lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(list_kernel, dim3(L.list_blocks), dim3(csm::kBlock), L.lds_bytes, L.stream, L.jobs_dev,
+                           L.cbx, L.groups, L.lane_map, csm::BlockBase{ L.row_base, L.cb_base, L.ncb }, L.items,
+                           L.item_count);
+        return hipGetLastError();
+    }
     auto kernel = L.fp32 ? csm::k_score_jointf_batch<LS, R> : csm::k_score_joint_batch<LS, R>;
     const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(kernel), L.lds_bytes);
     if (e != hipSuccess)
@@ -1078,10 +1123,18 @@ int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, i
     return (int)hipGetLastError();
 }
 
+int launch_bound_select(hipStream_t stream, const ScoreJob* jobs_dev, int n_jobs, int ncb, int split_cb,
+                        uint32_t* items0, uint32_t* items1, uint32_t* counts, uint32_t cap)
+{
+    hipLaunchKernelGGL(k_bound_select, dim3(n_jobs), dim3(256), 0, stream, jobs_dev, ncb, split_cb, items0, items1,
+                       counts, cap);
+    return (int)hipGetLastError();
+}
+
 int launch_joint_batch(const JointLaunch& L)
 {
 #ifdef CSM_FAST_BUILD
-    JOINT_CASE(150)
+    JOINT_CASE(150) JOINT_CASE(156)
 #else
     JOINT_CASE(86) JOINT_CASE(98) JOINT_CASE(118) JOINT_CASE(124) JOINT_CASE(130) JOINT_CASE(150)
     JOINT_CASE(156) JOINT_CASE(162) JOINT_CASE(182)
