@@ -1017,11 +1017,29 @@ __global__ __launch_bounds__(256) void k_bound_select(const ScoreJob* jobs, int 
             ++dropped;
         }
     }
+    /* one atomic per counter and workgroup: same-address atomics serialise at the memory side
+     * (63,000 of them cost 360 us per launch) */
     if (job.bound_stats) {
-        if (kept)
-            atomicAdd(job.bound_stats, kept);
-        if (dropped)
-            atomicAdd(job.bound_stats + 1, dropped);
+        __shared__ uint32_t tot[2];
+        if (tid == 0)
+            tot[0] = tot[1] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            kept += __shfl_xor(kept, d, 64);
+            dropped += __shfl_xor(dropped, d, 64);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&tot[0], kept);
+            atomicAdd(&tot[1], dropped);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (tot[0])
+                atomicAdd(job.bound_stats, tot[0]);
+            if (tot[1])
+                atomicAdd(job.bound_stats + 1, tot[1]);
+        }
     }
 }
 
