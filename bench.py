@@ -295,6 +295,8 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
     send = torch.zeros(block * rec_bytes, dtype=torch.uint8, device=dev)
     recv = torch.zeros(world * block * rec_bytes, dtype=torch.uint8, device=dev)
 
+    gather_events = []          # (start, end) around every timed all-gather, on `stream`
+
     def step():
         outs = ctx.bnb_match_batch(prepared, *LOOP_PARAMS, as_records=True)
         if world > 1:
@@ -305,7 +307,11 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
                 dist.all_gather_into_tensor(out, host)
                 recv.copy_(out)
             else:
-                dist.all_gather_into_tensor(recv, send)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                dist.all_gather_into_tensor(recv, send)       # RCCL; the current stream waits for it
+                e1.record(stream)
+                gather_events.append((e0, e1))
         return outs
 
     def fence():
@@ -320,6 +326,7 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
         fence()
         ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
         ctx.reset_kernel_timing()
+        del gather_events[:]
         t0 = time.perf_counter()
         for _ in range(args.steps):
             outs = step()
@@ -327,6 +334,7 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
         dt = time.perf_counter() - t0
     ctx.enable_kernel_timing(False)
     fine_ms, fine_n = ctx.kernel_time("score_fine")
+    gather_ms = [a.elapsed_time(b) for a, b in gather_events]
     leaves_local = outs.total("candidates")
     if world > 1:
         tt = torch.tensor([dt, float(leaves_local)], dtype=torch.float64, device=None if rehearse else dev)
@@ -366,7 +374,12 @@ def run_loop_workload(args, rank, world, dev, dev_index, rehearse, stream, n_tot
                        "leaves_per_step": leaves, "found": found,
                        "parallelism": "contiguous query blocks per GPU, one all-gather of 48-B records "
                                       "per step (%s)" % ("gloo rehearsal" if rehearse else "RCCL")
-                       if world > 1 else "single GPU"},
+                       if world > 1 else "single GPU",
+                       "exchange": {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank": block * rec_bytes,
+                                    "all_gather_ms_per_step_rank0": (sum(gather_ms) / len(gather_ms)) if gather_ms else None,
+                                    "all_gather_ms_max_rank0": max(gather_ms) if gather_ms else None,
+                                    "note": "HIP events on the scoring stream around the collective, rank 0"}
+                       if world > 1 else None},
             "roofline": rl,
         }), flush=True)
     ctx.close()
@@ -424,7 +437,7 @@ def measure_loop_config(dev_index, n_sub, steps=5):
             "roofline": rl}
 
 
-def measure_config5(dev_index, runs=2):
+def measure_config5(dev_index, runs=2, warmup=1):
     """configs[4]: exhaustive global CSM, 2000x2000 @ 2.5 cm, +-10 m / +-180 deg at
     2.5 cm / 0.25 deg, 1080 beams, L = 4: 9.3e8 candidate poses per query."""
     import torch
@@ -437,7 +450,8 @@ def measure_config5(dev_index, runs=2):
     t_up = time.perf_counter() - t0
     args = (5, case["geom"], case["angles"], case["ranges"], case["rel_pose"], case["init_pose"],
             20.0, 20.0, 2 * math.pi, 4, 0.0, 0.0)
-    out = ctx.correlative_match(*args)          # builds box-max(4), warms up
+    for _ in range(max(1, warmup)):
+        out = ctx.correlative_match(*args)          # the first call builds box-max(4)
     ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
     ctx.reset_kernel_timing()
     torch.cuda.synchronize()
@@ -472,7 +486,7 @@ def measure_config5(dev_index, runs=2):
                          "logical_hbm_frac": 2.0 * N_BEAMS * cands / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else None}}
 
 
-def measure_config2_latency(dev_index, wl, reps=30):
+def measure_config2_latency(dev_index, wl, reps=30, warmup=3):
     """What one frontend caller sees: csm_correlative_match per scan, scan in host
     memory, projection on the device, summary back on the host."""
     from csm_hip import api
@@ -480,19 +494,38 @@ def measure_config2_latency(dev_index, wl, reps=30):
     ctx = api.Context(dev_index)
     ctx.upload_grid(1, wl["grid"])
     samples = []
-    for i in range(reps + 3):
+    cands = 0
+    t_all = 0.0
+    for i in range(reps + warmup):
+        if i == warmup:
+            ctx.lib.csm_enable_kernel_timing(ctx._ctx, 1)
+            ctx.reset_kernel_timing()
+            t_all = time.perf_counter()
         sc = wl["scans"][i % len(wl["scans"])]
         t0 = time.perf_counter()
         out = ctx.correlative_match(1, wl["geom"], sc["angles"], sc["ranges"], sc["rel_pose"],
                                     sc["init_pose"], rx, ry, rt, L, 0.0, 0.0)
         samples.append(time.perf_counter() - t0)
+        if i >= warmup:
+            cands += out["candidates"]
+    t_all = time.perf_counter() - t_all
+    ctx.enable_kernel_timing(False)
+    kernels = {}
+    for name in ("project", "bin", "score_coarse", "score_fine", "argmax", "finalize"):
+        ms, n = ctx.kernel_time(name)
+        if n:
+            kernels[name] = ms / n * 1e3
     ctx.close()
-    samples = sorted(samples[3:])
+    samples = sorted(samples[warmup:])
     med = samples[len(samples) // 2]
     return {"workload": "configs[1], one query per call: csm_correlative_match, host-inclusive "
                         "(17 KB up, projection + search on device, 48-B record back)",
             "latency_ms_median": med * 1e3, "latency_ms_min": samples[0] * 1e3,
-            "value": out["candidates"] / med, "unit": "candidate poses/s", "reps": reps}
+            "latency_ms_p90": samples[int(0.9 * (len(samples) - 1))] * 1e3,
+            "value": out["candidates"] / med, "unit": "candidate poses/s", "reps": reps,
+            "total_s": t_all, "candidates_total": cands, "kernel_us_per_query": kernels,
+            "note": "kernel_us_per_query is measured with HIP events around every launch, which itself costs "
+                    "host time: the latency figures of a run that collects them are upper bounds"}
 
 
 # ------------------------------------------------------------------ map workload (not the BASELINE metric)
@@ -795,7 +828,11 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
                     cfgs[name] = fn()
                 except Exception as e:          # a side measurement must not lose the headline line
                     cfgs[name] = {"error": repr(e)}
-            out["configs"] = cfgs
+            # inside "config": the driver's parser keeps that object (a top-level "configs" key was dropped)
+            out["config"]["side_runs"] = cfgs
+            out["config"]["side_runs_summary"] = {
+                k: {kk: v[kk] for kk in ("value", "unit", "ms_per_step", "ms_per_query", "latency_ms_median") if kk in v}
+                for k, v in cfgs.items() if isinstance(v, dict)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
@@ -803,10 +840,47 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
         ctx.close()
 
 
+def run_side_workload(args, dev_index, which):
+    """`--workload config5` / `--workload latency` as lines of their own (the same contract):
+    a step is one query (one csm_correlative_match call, host-inclusive)."""
+    if which == "config5":
+        d = measure_config5(dev_index, runs=args.steps, warmup=max(1, args.warmup))
+        total_s = d["ms_per_query"] * 1e-3 * args.steps
+        ms_step = d["ms_per_query"]
+        value = d["value"]
+        roof = d["roofline"]
+    else:
+        wl = make_workload(0, 64)
+        d = measure_config2_latency(dev_index, wl, reps=args.steps, warmup=max(3, args.warmup))
+        total_s = d["total_s"]
+        ms_step = d["total_s"] / args.steps * 1e3
+        value = d["candidates_total"] / d["total_s"]
+        fine_us = d["kernel_us_per_query"].get("score_fine", 0.0)
+        sc = wl["scans"][0]
+        wx, wy, wt = sc["win"]
+        L = wl["params"][3]
+        nx, ny = -(-(2 * wx + 1) // L) * L, -(-(2 * wy + 1) // L) * L
+        gathers = cell_entries(sc["col"], sc["row"], 400, 400, -wx, -wy, -wx + nx - 1, -wy + ny - 1) * nx * ny
+        ach = 4.0 * gathers / (fine_us * 1e-6) / 1e9 if fine_us else None
+        roof = {"bound": "lds", "kernel": "k_score_pairs (fine level of one window, tile-split)", "unit": "GB/s",
+                "peak": LDS_PEAK_GBS, "achieved": ach, "frac": ach / LDS_PEAK_GBS if ach else None,
+                "avg_launch_us": fine_us, "traffic": None,
+                "note": "a single 0.87-M-pose window is latency-bound: six launches and two copies around "
+                        "~50 us of scoring; frac is the fine launch's share of the LDS read peak"}
+    print(json.dumps({
+        "metric": METRIC, "value": value, "unit": "candidate poses/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": d["workload"], "step": "one csm_correlative_match call (host-inclusive)",
+                   "timed_s": total_s, "detail": {k: v for k, v in d.items() if k not in ("roofline", "workload")}},
+        "roofline": roof}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="default: 20 (csm, loop workloads), 40 queries (config5), 12000 queries (latency)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning-off", type=int, default=0,
@@ -816,7 +890,7 @@ def main():
                          "(configs[1] workload; 0 = none)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the short side runs of configs[2], [3] at N = 1, [4] and the single-query latency")
-    ap.add_argument("--workload", choices=["auto", "csm", "loop", "loop4", "map"], default="auto",
+    ap.add_argument("--workload", choices=["auto", "csm", "loop", "loop4", "map", "config5", "latency"], default="auto",
                     help="auto (default): csm at N = 1, loop4 at N > 1. csm: BASELINE configs[1] per GPU "
                          "(replicas). loop: configs[2], 256 candidate submaps per GPU. loop4: configs[3], 2048 "
                          "submaps sharded over the ranks (strong scaling) + all-gather. map: the frontend "
@@ -850,8 +924,14 @@ def main():
     workload = args.workload
     if workload == "auto":
         workload = "csm" if world == 1 else "loop4"
+    if args.steps is None:
+        args.steps = {"config5": 40, "latency": 12000}.get(workload, 20)
     stream = torch.cuda.Stream(dev)
-    if workload == "map":
+    if workload in ("config5", "latency"):
+        if world != 1:
+            raise SystemExit("--workload %s is a single-GPU line" % workload)
+        run_side_workload(args, dev_index, workload)
+    elif workload == "map":
         run_map_workload(args, rank, world, dev, dev_index, rehearse)
     elif workload in ("loop", "loop4"):
         n_total = 2048 if workload == "loop4" else 256 * world

@@ -183,6 +183,18 @@ int  csm_synchronize(csm_ctx* ctx);
  *  src/mapping/scan_matcher_correlative_fpga.cpp:261-262) ---- */
 int  csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense,
                      int32_t rows, int32_t cols);
+/* The same from the reference's own storage, without the host-side flatten: GridMap<T> keeps
+ * block_rows x block_cols blocks of 2^log2_block x 2^log2_block uint16, row-major inside a block,
+ * each allocated or not (inc/grid_map_new/grid_map.hpp:255-263: mBlocks, mLog2BlockSize, mBlockRows,
+ * mBlockCols; inc/grid_map_new/grid_binary_bayes.hpp:197-202: mValues). blocks[br * block_cols + bc]
+ * points at a block's values or is NULL for an unallocated block. The library packs the allocated
+ * blocks into pinned staging (one copy), de-blocks on the device into the dense level
+ * GridMap::CopyValues (src/grid_map_new/grid_map.cpp:289-350, 439-457) would have produced
+ * (rows = block_rows << log2_block; unallocated blocks read 0), and keeps the allocation
+ * bitmap for the cost function (what csm_set_block_allocation would be given). The blocks are
+ * borrowed for the duration of the call. */
+int  csm_upload_grid_blocks(csm_ctx* ctx, uint64_t map_id, const uint16_t* const* blocks,
+                            int32_t block_rows, int32_t block_cols, int32_t log2_block);
 int  csm_has_grid(csm_ctx* ctx, uint64_t map_id);   /* 1 / 0 */
 int  csm_release_grid(csm_ctx* ctx, uint64_t map_id);
 

@@ -149,6 +149,7 @@ SIGNATURES = {
     "csm_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "csm_synchronize": (C.c_int, [_ctx]),
     "csm_upload_grid": (C.c_int, [_ctx, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32]),
+    "csm_upload_grid_blocks": (C.c_int, [_ctx, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "csm_has_grid": (C.c_int, [_ctx, C.c_uint64]),
     "csm_release_grid": (C.c_int, [_ctx, C.c_uint64]),
     "csm_build_pyramid": (C.c_int, [_ctx, C.c_uint64, _P(C.c_int32), C.c_int32]),

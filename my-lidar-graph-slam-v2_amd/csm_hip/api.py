@@ -198,6 +198,14 @@ class Context:
         self._check(self.lib.csm_upload_grid(self._ctx, map_id, _ptr(g), g.shape[0], g.shape[1]))
         self.shapes[map_id] = g.shape
 
+    def upload_grid_blocks(self, map_id, blocks, block_rows, block_cols, log2_block):
+        """Block-sparse upload (the reference's own storage): blocks[br * block_cols + bc] is a
+        (2^k, 2^k) uint16 array or None for an unallocated block."""
+        keep = [None if b is None else np.ascontiguousarray(b, dtype=np.uint16) for b in blocks]
+        ptrs = (C.c_void_p * len(keep))(*[None if b is None else b.ctypes.data for b in keep])
+        self._check(self.lib.csm_upload_grid_blocks(self._ctx, map_id, ptrs, block_rows, block_cols, log2_block))
+        self.shapes[map_id] = (block_rows << log2_block, block_cols << log2_block)
+
     def has_grid(self, map_id):
         return bool(self.lib.csm_has_grid(self._ctx, map_id))
 

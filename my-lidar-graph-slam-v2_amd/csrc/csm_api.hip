@@ -1628,11 +1628,18 @@ int resolve_literal(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan
 
 /* Finish a window whose fast-path record carries a tie or an edge-band flag. */
 int resolve_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
-                   const int32_t* col_dev, const int32_t* row_dev, csm_result* out_dev)
-{
+                   const int32_t* col_dev, const int32_t* row_dev, csm_result* out_dev,
+                   const csm_result* have = nullptr, bool* changed = nullptr)
+{   /* have: the record as already read back by the caller (saves a copy and a wait per query) */
     csm_result r;
-    HIP_TRY(ctx, hipMemcpyAsync(&r, out_dev, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (have) {
+        r = *have;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(&r, out_dev, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (changed)
+        *changed = (!(r.flags & CSM_FLAG_EDGE_BAND) && r.tie_count > 1) || (r.flags & CSM_FLAG_EDGE_BAND);
     int rc;
     if (!(r.flags & CSM_FLAG_EDGE_BAND) && r.tie_count > 1) {
         if ((rc = resolve_ties(ctx, g, w, p, col_dev, row_dev, out_dev))) return rc;
@@ -1844,6 +1851,83 @@ int csm_upload_grid(csm_ctx* ctx, uint64_t map_id, const uint16_t* dense, int32_
     }
     HIP_TRY(ctx, hipMemcpyAsync(base.cells, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      /* the staging buffer is reused by the next upload */
+    return CSM_OK;
+}
+
+int csm_upload_grid_blocks(csm_ctx* ctx, uint64_t map_id, const uint16_t* const* blocks, int32_t block_rows,
+                           int32_t block_cols, int32_t log2_block)
+{
+    if (!ctx || !blocks || block_rows < 1 || block_cols < 1 || log2_block < 0 || log2_block > 10 ||
+        ((int64_t)block_rows << log2_block) > 65536 || ((int64_t)block_cols << log2_block) > 65536)
+        return fail(ctx, CSM_EINVAL, "csm_upload_grid_blocks: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = block_rows << log2_block, cols = block_cols << log2_block;
+    const int n_blocks = block_rows * block_cols;
+    const size_t block_cells = (size_t)1 << (2 * log2_block);
+    int n_alloc = 0;
+    for (int b = 0; b < n_blocks; ++b)
+        n_alloc += blocks[b] != nullptr;
+    DeviceGrid& g = ctx->grids[map_id];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(g, false);
+    g.rows = rows;
+    g.cols = cols;
+    g.pitch = (cols + 7) & ~7;
+    Level base;
+    const size_t bytes = (size_t)rows * g.pitch * 2;
+    if (hipMalloc(reinterpret_cast<void**>(&base.cells), bytes) != hipSuccess) {
+        ctx->grids.erase(map_id);
+        return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    }
+    base.win = 1;
+    base.owned = true;
+    base.cap = bytes;
+    g.levels.push_back(base);
+    if (hipMalloc(reinterpret_cast<void**>(&g.alloc), (size_t)n_blocks + 64) != hipSuccess)
+        return fail(ctx, CSM_ENOMEM, "hipMalloc(%d) failed", n_blocks + 64);
+    g.alloc_cap = (size_t)n_blocks + 64;
+    /* pinned staging: [first known row, column][slot of every block][the allocated blocks]; one DMA */
+    const size_t head = (((size_t)(2 + n_blocks) * 4) + 255) & ~(size_t)255;
+    const size_t stage_bytes = head + (size_t)n_alloc * block_cells * 2;
+    if (stage_bytes > ctx->pin_cap) {
+        if (ctx->pin)
+            (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+        if (hipHostMalloc(&ctx->pin, stage_bytes + stage_bytes / 4, hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipHostMalloc(%zu) failed", stage_bytes);
+        ctx->pin_cap = stage_bytes + stage_bytes / 4;
+    }
+    int32_t* h_head = reinterpret_cast<int32_t*>(ctx->pin);
+    h_head[0] = rows;                       /* "no known cell": what csm_upload_grid reports */
+    h_head[1] = cols;
+    uint16_t* h_packed = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(ctx->pin) + head);
+    int next = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        h_head[2 + b] = blocks[b] ? next : -1;
+        if (blocks[b])
+            std::memcpy(h_packed + (size_t)next++ * block_cells, blocks[b], block_cells * 2);
+    }
+    int rc = ensure(ctx, ctx->scratch, stage_bytes);
+    if (rc)
+        return rc;
+    char* d_stage = reinterpret_cast<char*>(ctx->scratch.p);
+    HIP_TRY(ctx, hipMemcpyAsync(d_stage, ctx->pin, stage_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const int grid_blocks = (int)std::min<size_t>(4096, ((size_t)rows * g.pitch + 255) / 256);
+    hipLaunchKernelGGL(k_deblock, dim3(grid_blocks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint16_t*>(d_stage + head), reinterpret_cast<const int32_t*>(d_stage) + 2,
+                       log2_block, block_cols, rows, cols, g.pitch, base.cells, g.alloc, n_blocks,
+                       reinterpret_cast<int32_t*>(d_stage));
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t known[2] = { rows, cols };
+    HIP_TRY(ctx, hipMemcpyAsync(known, d_stage, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    g.known_r0 = known[0];
+    g.known_c0 = known[1];
+    g.alloc_log2 = log2_block;
+    g.alloc_bcols = block_cols;
+    g.alloc_user = true;
+    g.alloc_stale = false;
     return CSM_OK;
 }
 
@@ -2214,10 +2298,19 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
         HIP_TRY(ctx, hipGetLastError());
     }
     if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
-    if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
+    /* ONE read-back and one wait per query (record + uncertified count); the exact paths run only
+     * for a record that carries a tie or an edge-band flag */
     Tail tail;
     HIP_TRY(ctx, hipMemcpyAsync(&tail, tail_dev, sizeof(tail), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        bool changed = false;
+        if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, &tail.res, &changed))) return rc;
+        if (changed) {
+            HIP_TRY(ctx, hipMemcpyAsync(&tail.res, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     out->raw = tail.res;
     const uint32_t n_unc = tail.n_unc;
     if (n_unc > 0) {

@@ -22,6 +22,27 @@
 #include <dlfcn.h>
 
 #include <set>
+#include <type_traits>
+
+/* The RCCL entry points are taken with dlsym (librccl is only needed when a group spans several
+ * devices) through hand-declared pointer types. Where the header is present at build time the
+ * declarations are checked against it, so that a changed signature breaks the build, not a call. */
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) &&
+                  sizeof(ncclComm_t) == sizeof(void*) && (int)ncclSuccess == 0 && (int)ncclUint8 == 1,
+              "csm_group's RCCL pointer types assume int-sized enums, ncclSuccess = 0, ncclUint8 = 1");
+static_assert(std::is_same<decltype(&ncclAllGather),
+                           ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value,
+              "ncclAllGather signature changed");
+static_assert(std::is_same<decltype(&ncclCommInitAll), ncclResult_t (*)(ncclComm_t*, int, const int*)>::value,
+              "ncclCommInitAll signature changed");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value,
+              "ncclCommDestroy signature changed");
+static_assert(std::is_same<decltype(&ncclGroupStart), ncclResult_t (*)()>::value &&
+                  std::is_same<decltype(&ncclGroupEnd), ncclResult_t (*)()>::value,
+              "ncclGroupStart / ncclGroupEnd signature changed");
+#endif
 
 struct csm_group {
     std::vector<csm_ctx*> members;
@@ -247,6 +268,15 @@ int csm_allgather_results(csm_group* g, csm_result* host_out)
     const auto t0 = std::chrono::steady_clock::now();
     const int block = (n + m - 1) / m;                       /* padded block, records */
     const size_t block_bytes = (size_t)block * sizeof(csm_result);
+    /* An error return must not leave copies or a collective pending on the members' streams (the
+     * caller may free or reuse the buffers): every member's stream is drained first. */
+    auto drained = [&](int code) {
+        for (int k = 0; k < m; ++k) {
+            (void)hipSetDevice(g->devices[k]);
+            (void)hipStreamSynchronize(g->members[k]->stream);
+        }
+        return code;
+    };
     /* every member: its block (device records of its last batch call) into a padded send buffer */
     for (int k = 0; k < m; ++k) {
         csm_ctx* c = g->members[k];
@@ -254,32 +284,34 @@ int csm_allgather_results(csm_group* g, csm_result* host_out)
             return gfail(g, CSM_EIO, "hipSetDevice(%d) failed", g->devices[k]);
         int rc;
         if ((rc = ensure(c, g->send[k], block_bytes)) || (rc = ensure(c, g->recv[k], block_bytes * m)))
-            return gfail(g, rc, "member %d: %s", k, csm_last_error(c));
+            return drained(gfail(g, rc, "member %d: %s", k, csm_last_error(c)));
         int32_t lo = 0, hi = 0;
         csm_shard_bounds(n, k, m, &lo, &hi);
         if (hipMemsetAsync(g->send[k].p, 0, block_bytes, c->stream) != hipSuccess)
-            return gfail(g, CSM_EIO, "hipMemsetAsync failed");
+            return drained(gfail(g, CSM_EIO, "hipMemsetAsync failed"));
         if (hi > lo) {
             if (c->rec_n != hi - lo || !c->rec_dev.p)
-                return gfail(g, CSM_ENOENT, "member %d holds %d records, its block has %d", k, c->rec_n,
-                             hi - lo);
+                return drained(gfail(g, CSM_ENOENT, "member %d holds %d records, its block has %d", k, c->rec_n,
+                                     hi - lo));
             if (hipMemcpyAsync(g->send[k].p, c->rec_dev.p, (size_t)(hi - lo) * sizeof(csm_result),
                                hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-                return gfail(g, CSM_EIO, "hipMemcpyAsync failed");
+                return drained(gfail(g, CSM_EIO, "hipMemcpyAsync failed"));
         }
     }
     if (g->use_rccl) {
         int rc = group_init_comms(g);
         if (rc)
-            return rc;
+            return drained(rc);
+        /* a group that was opened is always closed, whatever a call inside it returned */
         int res = g->p_group_start();
+        const bool opened = res == 0;
         for (int k = 0; k < m && res == 0; ++k)
             res = g->p_all_gather(g->send[k].p, g->recv[k].p, block_bytes, /* ncclUint8 */ 1, g->comms[k],
                                   g->members[k]->stream);
-        const int res_end = g->p_group_end();
+        const int res_end = opened ? g->p_group_end() : 0;
         if (res != 0 || res_end != 0)
-            return gfail(g, CSM_EIO, "ncclAllGather failed: %s",
-                         g->p_error_string ? g->p_error_string(res ? res : res_end) : "?");
+            return drained(gfail(g, CSM_EIO, "ncclAllGather failed: %s",
+                                 g->p_error_string ? g->p_error_string(res ? res : res_end) : "?"));
     } else {
         /* one member, or members sharing a device: the blocks go through the host */
         std::vector<char> host(block_bytes * m);
@@ -288,12 +320,12 @@ int csm_allgather_results(csm_group* g, csm_result* host_out)
             if (hipMemcpyAsync(host.data() + block_bytes * k, g->send[k].p, block_bytes,
                                hipMemcpyDeviceToHost, g->members[k]->stream) != hipSuccess ||
                 hipStreamSynchronize(g->members[k]->stream) != hipSuccess)
-                return gfail(g, CSM_EIO, "device to host copy failed");
+                return drained(gfail(g, CSM_EIO, "device to host copy failed"));
         }
         for (int k = 0; k < m; ++k) {
             (void)hipSetDevice(g->devices[k]);
             if (hipMemcpy(g->recv[k].p, host.data(), block_bytes * m, hipMemcpyHostToDevice) != hipSuccess)
-                return gfail(g, CSM_EIO, "host to device copy failed");
+                return drained(gfail(g, CSM_EIO, "host to device copy failed"));
         }
     }
     /* member 0's gathered buffer, padding dropped, in query order */
@@ -301,11 +333,11 @@ int csm_allgather_results(csm_group* g, csm_result* host_out)
     (void)hipSetDevice(g->devices[0]);
     if (hipMemcpyAsync(all.data(), g->recv[0].p, block_bytes * m, hipMemcpyDeviceToHost,
                        g->members[0]->stream) != hipSuccess)
-        return gfail(g, CSM_EIO, "device to host copy failed");
+        return drained(gfail(g, CSM_EIO, "device to host copy failed"));
     for (int k = 0; k < m; ++k) {
         (void)hipSetDevice(g->devices[k]);
         if (hipStreamSynchronize(g->members[k]->stream) != hipSuccess)
-            return gfail(g, CSM_EIO, "hipStreamSynchronize failed");
+            return drained(gfail(g, CSM_EIO, "hipStreamSynchronize failed"));
     }
     if (host_out)
         for (int k = 0; k < m; ++k) {
@@ -316,6 +348,7 @@ int csm_allgather_results(csm_group* g, csm_result* host_out)
         }
     g->last_gather_us =
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    g->err.clear();
     return CSM_OK;
 }
 

@@ -810,6 +810,50 @@ __global__ __launch_bounds__(kBlock) void k_score_batch(const ScoreJob* jobs, in
 
 /* ------------------------------------------------------------------ K1, pair-row layout */
 
+/* Block-sparse upload (csm_upload_grid_blocks): the reference grid is block_rows x block_cols
+ * blocks of 2^k x 2^k uint16, row-major inside a block, unallocated blocks absent
+ * (inc/grid_map_new/grid_map.hpp:255-263, grid_binary_bayes.hpp:197-202). `packed` holds the allocated
+ * blocks back to back, slot[b] the position of block b in it or -1. Writes the dense pitched level
+ * (what GridMap::CopyValues, src/grid_map_new/grid_map.cpp:289-350, 439-457, would have produced on the
+ * host: unallocated blocks read 0), the per-block allocation bytes (GridMap::IsAllocated) and the first
+ * row / column that hold a known cell. */
+__global__ __launch_bounds__(256) void k_deblock(const uint16_t* __restrict__ packed, const int32_t* __restrict__ slot,
+                                                int log2_block, int block_cols, int rows, int cols, int pitch,
+                                                uint16_t* __restrict__ cells, uint8_t* __restrict__ alloc,
+                                                int n_blocks, int32_t* __restrict__ known_first)
+{
+    const int mask = (1 << log2_block) - 1;
+    const size_t total = (size_t)rows * pitch;
+    int kr = 0x7fffffff, kc = 0x7fffffff;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / pitch), c = (int)(i % pitch);
+        uint16_t v = 0;
+        if (c < cols) {
+            const int s = slot[(r >> log2_block) * block_cols + (c >> log2_block)];
+            if (s >= 0)
+                v = packed[((size_t)s << (2 * log2_block)) + ((size_t)(r & mask) << log2_block) + (c & mask)];
+        }
+        cells[i] = v;
+        if (v) {
+            kr = min(kr, r);
+            kc = min(kc, c);
+        }
+    }
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n_blocks; b += gridDim.x * 256)
+        alloc[b] = slot[b] >= 0 ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kr = min(kr, __shfl_xor(kr, d, 64));
+        kc = min(kc, __shfl_xor(kc, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kr != 0x7fffffff)
+            atomicMin(known_first, kr);
+        if (kc != 0x7fffffff)
+            atomicMin(known_first + 1, kc);
+    }
+}
+
 /* Expanded, zero-padded, pair-row copy of a grid level: slot (k, c) = 8 bytes =
  * cells (2k - pad, c - pad) and (2k + 1 - pad, c - pad) as v + (v != 0) << 23 (24
  * bits: one v_mad_u32_u24 per gather adds value sum and known count together).
