@@ -73,6 +73,8 @@ typedef struct csm_ctx csm_ctx;
 #define CSM_TUNE_NO_JOINT          128u   /* batch fine kernel: per-slice entry lists (round-2 form) */
 #define CSM_TUNE_NO_BOUND_PASS     256u   /* no packed-fp32 bound pass: the exact integer kernel scores
                                              every candidate block */
+#define CSM_TUNE_NO_TWO_PHASE      512u   /* single windows are always searched exhaustively */
+#define CSM_TUNE_FORCE_TWO_PHASE  1024u   /* ... always coarse-first (default: by window size) */
 
 typedef struct {
     int32_t  device_id;          /* HIP device ordinal */
@@ -305,6 +307,20 @@ int  csm_score_windows_dump_dev(csm_ctx* ctx, int32_t n, const uint64_t* map_ids
                                 const int32_t* const* hit_row_dev, csm_result* out_dev,
                                 uint32_t* const* dump_s_dev, uint16_t* const* dump_k_dev,
                                 float* const* dump_f_dev);
+/* What the last single-window search (csm_correlative_match) evaluated. Large windows are searched
+ * coarse-first (scan_matcher_correlative.cpp:176-192 is the reference's pruning): every
+ * coarse node is scored, then the fine level only on the candidate blocks that hold an eligible
+ * coarse node reaching the best fine score found under the best coarse node. SURVEY 8(d) asks for
+ * the EVALUATED poses of a pruned search next to the nominal window. */
+typedef struct {
+    int64_t nominal_candidates;        /* (2 win_theta + 1) * X_ext * Y_ext */
+    int64_t coarse_nodes_scored;       /* 0: exhaustive search, no coarse pass needed */
+    int64_t fine_candidates_scored;    /* candidates of the fine blocks scored (whole blocks) */
+    int32_t two_phase;                 /* 1: coarse-first */
+    int32_t reserved;
+    int64_t blocks_scored, blocks_skipped;
+} csm_search_info;
+int  csm_last_search_info(csm_ctx* ctx, csm_search_info* out);
 /* Two-pass fine level of the batch entries: candidate blocks the exact
  * integer kernel scored / skipped after the packed-fp32 bound pass since the last call
  * (synchronises the context's stream; resets the counters). */

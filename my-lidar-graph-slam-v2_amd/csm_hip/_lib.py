@@ -37,7 +37,14 @@ class Config(C.Structure):
 TUNE_NO_LANE_MAP, TUNE_NO_XCD_MAP, TUNE_NO_PAIR_TAIL, TUNE_NO_TWO_SLICES = 1, 2, 4, 8
 TUNE_NO_THETA_MAJOR, TUNE_NO_TILE_SPLIT, TUNE_MAP_HOST_PROJECTION, TUNE_NO_JOINT = 16, 32, 64, 128
 TUNE_NO_BOUND_PASS = 256
+TUNE_NO_TWO_PHASE, TUNE_FORCE_TWO_PHASE = 512, 1024
 GROUP_FORCE_RCCL = 1
+
+
+class SearchInfo(C.Structure):
+    _fields_ = [("nominal_candidates", C.c_int64), ("coarse_nodes_scored", C.c_int64),
+                ("fine_candidates_scored", C.c_int64), ("two_phase", C.c_int32), ("reserved", C.c_int32),
+                ("blocks_scored", C.c_int64), ("blocks_skipped", C.c_int64)]
 
 
 class Geometry(C.Structure):
@@ -179,6 +186,7 @@ SIGNATURES = {
     "csm_score_windows_dump_dev": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "csm_bound_pass_stats": (C.c_int, [_ctx, _P(C.c_uint64), _P(C.c_uint64)]),
+    "csm_last_search_info": (C.c_int, [_ctx, C.c_void_p]),
     "csm_resolve_window_dev": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "csm_score_window_dump": (C.c_int, [_ctx, C.c_uint64, _P(Window), C.c_void_p,

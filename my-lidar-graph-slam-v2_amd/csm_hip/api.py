@@ -312,6 +312,12 @@ class Context:
         self._check(self.lib.csm_score_windows_dump_dev(self._ctx, n, ids, wins, cols, rows, C.c_void_p(out_ptr),
                                                         arr(dump_s_ptrs), arr(dump_k_ptrs), arr(dump_f_ptrs)))
 
+    def last_search_info(self):
+        """What the last correlative_match() evaluated (nominal / coarse nodes / fine candidates)."""
+        info = L.SearchInfo()
+        self._check(self.lib.csm_last_search_info(self._ctx, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
+
     def bound_pass_stats(self):
         """(candidate blocks the exact kernel scored, blocks it skipped after the fp32 bound
         pass) since the last call."""

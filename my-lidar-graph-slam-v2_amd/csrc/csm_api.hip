@@ -28,6 +28,7 @@
 
 #include "csm_kernels.hip"
 #include "csm_joint.hpp"
+#include "csm_phase.hpp"
 #include "csm_map_kernels.hip"
 #include "csm_cost_kernels.hip"
 
@@ -62,8 +63,21 @@ struct Level {
     size_t    cap = 0;           /* bytes allocated (owned levels) */
 };
 
+struct DeviceGrid;
+
+/* Phase-major copy of a box-max(L) level of a map (k_phase_map): the grid the coarse pass of the
+ * two-phase search scores on. */
+struct PhaseMap {
+    std::unique_ptr<DeviceGrid> grid;
+    int hp = 0, wp = 0, pad = 0;
+    const uint16_t* built_from = nullptr;   /* the level's buffer and the base epoch it was built at */
+    uint64_t epoch = 0;
+};
+
 struct DeviceGrid {
     int rows = 0, cols = 0, pitch = 0;
+    uint64_t base_epoch = 0;          /* bumped whenever level 0's cells change */
+    std::map<int, PhaseMap> phase;    /* by box-max window L */
     int known_r0 = 0, known_c0 = 0;   /* first row / column holding a known cell */
     std::vector<Level> levels;   /* levels[0] is the uploaded grid */
     /* expanded, zero-padded pair-row copy of level 0 for the fine kernel's LDS-DMA
@@ -108,6 +122,7 @@ struct Tuning {
     bool two_slices = true;    /* batch fine kernel takes two theta slices per workgroup */
     bool joint = true;         /* ... on joint entry lists of the two slices (k_binj / k_score_joint_batch) */
     bool bound_pass = true;    /* ... preceded by the packed-fp32 bound pass; the exact kernel skips blocks that cannot win */
+    int  two_phase = 0;        /* single large windows coarse-first: 0 by size, 1 always, -1 never */
     bool tile_split = true;    /* small single windows: tile list split over blockIdx.z */
     bool map_host_projection = false;   /* map building: hit points on the host */
     int  theta_major = -1;     /* -1: by launch size */
@@ -126,7 +141,9 @@ struct csm_ctx {
     double* lut_dev = nullptr;
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
-    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out, b_abest, bound_stats, b_items;
+    DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out, b_abest, bound_stats, b_items, tp_items, ph_hits;
+    const uint32_t* tp_count_dev = nullptr;      /* [3] items / blocks kept / dropped of the last two-phase search */
+    int64_t last_coarse_nodes = 0, last_fine_candidates = 0, last_nominal = 0, last_block_candidates = 0;   /* csm_last_search_info */
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     std::map<std::array<int, 4>, uint16_t*> lane_maps;   /* lane_map_for(): (cbx, groups, R, LS) -> device table */
     void* pin = nullptr;          /* pinned staging of csm_upload_grid */
@@ -910,6 +927,33 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
     return CSM_OK;
 }
 
+#define CALL_PAIRS_LIST(LS, RR, WW)                                                    \
+    do {                                                                               \
+        int rc_ = set_lds(ctx, k_score_pairs_list<LS, RR, WW>, lds);                   \
+        if (rc_)                                                                       \
+            return rc_;                                                                \
+        hipLaunchKernelGGL((k_score_pairs_list<LS, RR, WW>), dim3(blocks), dim3(kBlock), lds, ctx->stream, job, \
+                           pp.cbx, pp.groups, pp.ncb(), lane_map, items, count);       \
+    } while (0)
+
+/* the single-window pair kernel over a work list of (slice, candidate block) items */
+int launch_score_list(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, const uint32_t* items,
+                      const uint32_t* count, int blocks)
+{
+    if (!pp.pairs)
+        return fail(ctx, CSM_EINVAL, "internal: list launches need the pair kernel");
+    const size_t lds = pass_lds_bytes(pp);
+    bool launched = false;
+    const uint16_t* lane_map = nullptr;
+    if (int rc = lane_map_for(ctx, pp, &lane_map))
+        return rc;
+    PAIR_DISPATCH(CALL_PAIRS_LIST);
+    if (!launched)
+        return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
+    HIP_TRY(ctx, hipGetLastError());
+    return CSM_OK;
+}
+
 #define ARGMAX_CASE(LS, RR)                                                            \
     if (pp.lstride == LS && pp.R == RR) {                                              \
         hipLaunchKernelGGL((k_argmax<LS, RR>), grid, dim3(kBlock), 0, ctx->stream, job, \
@@ -1054,6 +1098,11 @@ DeviceGrid* find_grid(csm_ctx* ctx, uint64_t id)
 
 void free_levels(DeviceGrid& g, bool keep_base)
 {
+    for (auto& kv : g.phase)
+        if (kv.second.grid)
+            free_levels(*kv.second.grid, false);
+    g.phase.clear();
+    ++g.base_epoch;
     if (!keep_base) {
         if (g.xg)
             (void)hipFree(g.xg);
@@ -1254,10 +1303,24 @@ struct WindowOutputs {
 };
 
 /* The CSM pipeline on device-resident inputs; asynchronous. */
+/* Two-phase search (csm_phase_kernels.hip). mode 1: score the window and STORE every candidate's
+ * sums [n_theta][nx][ny] (the coarse pass, run on the level's phase-major copy), nothing else;
+ * mode 2: the fine level, its eligibility from such sums (level_s / level_k with strides nxs, nys),
+ * over the work list of the blocks that can still win. */
+struct TwoPhaseCtl {
+    int mode = 0;
+    uint32_t* level_s = nullptr;
+    uint32_t* level_k = nullptr;
+    int nxs = 0, nys = 0;
+    uint32_t stats[4] = { 0, 0, 0, 0 };      /* mode 2, filled on request: items, kept, dropped */
+};
+
 int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
                const int32_t* hit_col_dev, const int32_t* hit_row_dev,
-               csm_result* out_dev, const WindowOutputs* dumps, bool force_coarse = false)
+               csm_result* out_dev, const WindowOutputs* dumps, bool force_coarse = false,
+               TwoPhaseCtl* tp = nullptr)
 {
+    const int tp_mode = tp ? tp->mode : 0;
     if (w->coarse_level < 0 || w->coarse_level >= (int)g.levels.size())
         return fail(ctx, CSM_ENOENT, "coarse level %d not built", w->coarse_level);
     if (g.levels[w->coarse_level].stale)
@@ -1286,9 +1349,9 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         const long blocks = (long)ncb * p.n_theta;
         if (blocks < 384)
             fine_slices = (int)std::min<long>(4, std::max<long>(1, 492 / std::max<long>(1, blocks)));
-        if (!ctx->tune.tile_split)
+        if (!ctx->tune.tile_split || tp_mode)
             fine_slices = 1;
-        if (ctx->tune.fine_slices)
+        else if (ctx->tune.fine_slices)
             fine_slices = std::max(1, std::min(8, ctx->tune.fine_slices));
         if (fine_slices > 1) {
             /* the accumulators are zero between queries: cleared once when
@@ -1312,7 +1375,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     }
     uint32_t* flags = flag_words + (ctx->flag_toggle & 1u);
     uint32_t* flags_next = flag_words + ((ctx->flag_toggle + 1u) & 1u);
-    ctx->flag_toggle++;
+    if (tp_mode != 1)           /* the level pass sets no flag and has no finalize to clear one */
+        ctx->flag_toggle++;
 
     BinJob bj;
     std::memset(&bj, 0, sizeof(bj));
@@ -1341,7 +1405,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     bj.pair_mode = p.fine.pairs ? 1 : 0;
     bj.frame_shift = p.fine.pairs ? ((p.ny - 1) & 1) : 0;
     bj.sorted_rc = p.L > 1 ? reinterpret_cast<uint32_t*>(ctx->sorted_rc.p) : nullptr;
-    const bool coarse_exits = w->min_known <= 1 && !force_coarse;   /* unless a beam reaches the band */
+    const bool coarse_exits = w->min_known <= 1 && !force_coarse && tp_mode != 2;   /* unless a beam reaches the band */
     if (p.L > 1) {
         bj.n_band = 1;
         bj.band_win[0] = p.L;
@@ -1355,7 +1419,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBinBlock), lds, ctx->stream, bj);
         HIP_TRY(ctx, hipGetLastError());
     }
-    if (p.L > 1) {
+    if (p.L > 1 && tp_mode != 2) {
         /* the coarse pass accumulates with atomics: its sums are cleared first, but
          * only when it is going to run (k_zero_if_band reads the band flag k_bin set) */
         ZeroJob zj;
@@ -1386,7 +1450,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     base.flags = flags;
     base.min_known = w->min_known;
 
-    if (p.L > 1) {
+    if (p.L > 1 && tp_mode != 2) {
         ScoreJob cj = base;
         cj.cells = g.levels[w->coarse_level].cells;
         cj.nx = p.nxc;
@@ -1432,10 +1496,89 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         fj.elig[0].nxc = p.nxc;
         fj.elig[0].nyc = p.nyc;
         fj.elig_only_if_band = coarse_exits;
+        if (tp_mode == 2) {
+            fj.elig[0].k = tp->level_k;
+            fj.elig[0].s = tp->level_s;
+            fj.elig[0].nxc = tp->nxs;
+            fj.elig[0].nyc = tp->nys;
+        }
     } else {
         fj.check_own_known = 1;
     }
-    if (fine_slices > 1) {
+    if (tp_mode == 1) {
+        /* every candidate's sums, stored; no arg-max, no record */
+        fj.block_best = nullptr;
+        fj.check_own_known = 0;
+        fj.acc_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
+        fj.acc_k = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
+        fj.acc_x_major = 2;
+        tp->level_s = fj.acc_s;
+        tp->level_k = fj.acc_k;
+        tp->nxs = p.nx;
+        tp->nys = p.ny;
+        ScopedTimer tm(ctx, "score_coarse");
+        return launch_score(ctx, fj, p.fine, p.n_theta, 1);
+    }
+    if (tp_mode == 2) {
+        /* the blocks whose coarse bound reaches the best fine key under the best coarse node */
+        if (p.fine.ncb() > 4096 || (size_t)p.n_theta * tp->nxs * tp->nys >= (1u << 26) || p.n > 4096)
+            return fail(ctx, CSM_EINVAL, "internal: window too large for the two-phase work list");
+        const size_t n_blocks = nt * ncb;
+        if ((rc = ensure(ctx, ctx->tp_items, 64 + n_blocks * 4))) return rc;
+        unsigned long long* best2 = reinterpret_cast<unsigned long long*>(ctx->tp_items.p);
+        uint32_t* count = reinterpret_cast<uint32_t*>(best2 + 2);
+        uint32_t* items = count + 12;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tp_items.p, 0, 64, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->best.p, 0, n_blocks * sizeof(BlockBest), ctx->stream));
+        csm::TwoPhaseJob J;
+        std::memset(&J, 0, sizeof(J));
+        J.coarse_s = tp->level_s;
+        J.coarse_k = tp->level_k;
+        J.n_theta = p.n_theta;
+        J.nxc = p.nxc;
+        J.nyc = p.nyc;
+        J.nxs = tp->nxs;
+        J.nys = tp->nys;
+        J.L = p.L;
+        J.min_known = w->min_known;
+        J.cells = g.levels[0].cells;
+        J.rows = g.rows;
+        J.cols = g.cols;
+        J.pitch = g.pitch;
+        J.hit_col = hit_col_dev;
+        J.hit_row = hit_row_dev;
+        J.n_points = p.n;
+        J.x_lo = p.x_lo;
+        J.y_lo = p.y_lo;
+        J.nx = p.nx;
+        J.ny = p.ny;
+        J.cbx = p.fine.cbx;
+        J.cby = p.fine.groups * p.fine.R;
+        J.ncbx = p.fine.ncbx;
+        J.ncb = ncb;
+        J.flags = flags;
+        J.best = best2;
+        J.items = items;
+        J.count = count;
+        J.cap = (uint32_t)n_blocks;
+        {
+            ScopedTimer tm(ctx, "select");
+            int e = csm::launch_coarse_best(ctx->stream, J);
+            if (!e) e = csm::launch_fine_under_best(ctx->stream, J);
+            if (!e) e = csm::launch_mark_blocks(ctx->stream, J);
+            if (e)
+                return fail(ctx, CSM_EIO, "two-phase select launch failed: %s", hipGetErrorString((hipError_t)e));
+        }
+        {
+            ScopedTimer tm(ctx, "score_fine");
+            if ((rc = launch_score_list(ctx, fj, p.fine, items, count, (int)std::min<size_t>(n_blocks, 2048))))
+                return rc;
+        }
+        ctx->tp_count_dev = count;
+    }
+    if (tp_mode == 2) {
+        /* launched above */
+    } else if (fine_slices > 1) {
         /* small windows: too few workgroups to fill the chip, so the tile list
          * is split over blockIdx.z, the slices add their exact integer sums
          * with atomics, and a second pass does the arg-max */
@@ -1501,6 +1644,106 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     return CSM_OK;
 }
 
+
+/* The phase-major copy of box-max level `level` of g for coarse windows of up to `need` candidates
+ * per axis (its zero padding), built on first use and whenever the level changed. */
+int ensure_phase_map(csm_ctx* ctx, DeviceGrid& g, int level, int need, PhaseMap** out)
+{
+    const int L = g.levels[level].win;
+    PhaseMap& pm = g.phase[L];
+    const uint16_t* src = g.levels[level].cells;
+    if (pm.grid && pm.built_from == src && pm.epoch == g.base_epoch && pm.pad >= need + 2) {
+        *out = &pm;
+        return CSM_OK;
+    }
+    const int pad = std::max(need + 2, pm.pad);
+    const int rows_c = ceil_div(g.rows, L), cols_c = ceil_div(g.cols, L);
+    const int hp = rows_c + 2 * pad, wp = cols_c + 2 * pad;
+    if (!pm.grid)
+        pm.grid.reset(new DeviceGrid());
+    DeviceGrid& pg = *pm.grid;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(pg, false);
+    pg.rows = L * hp;
+    pg.cols = L * wp;
+    pg.pitch = (pg.cols + 7) & ~7;
+    pg.known_r0 = 0;
+    pg.known_c0 = 0;
+    Level base;
+    const size_t bytes = (size_t)pg.rows * pg.pitch * 2;
+    if (hipMalloc(reinterpret_cast<void**>(&base.cells), bytes) != hipSuccess)
+        return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    base.win = 1;
+    base.owned = true;
+    base.cap = bytes;
+    pg.levels.push_back(base);
+    const int e = csm::launch_phase_map(ctx->stream, src, g.rows, g.cols, g.pitch, L, hp, wp, pad, base.cells, pg.pitch);
+    if (e)
+        return fail(ctx, CSM_EIO, "k_phase_map launch failed: %s", hipGetErrorString((hipError_t)e));
+    pm.hp = hp;
+    pm.wp = wp;
+    pm.pad = pad;
+    pm.built_from = src;
+    pm.epoch = g.base_epoch;
+    *out = &pm;
+    return CSM_OK;
+}
+
+/* Is this window searched coarse-first? Large windows only (the coarse pass, the selection and a
+ * second binning cost more than they save on a window the exhaustive kernel finishes in 50 us). */
+bool wants_two_phase(const csm_ctx* ctx, const Plan& p)
+{
+    if (ctx->tune.two_phase < 0 || p.L < 2 || !p.fine.pairs || p.fine.ncb() > 4096 || p.n > 4096)
+        return false;
+    const size_t nodes = (size_t)p.n_theta * (p.nxc + 1) * (p.nyc + 1);
+    if (nodes >= (1u << 26))
+        return false;
+    return ctx->tune.two_phase > 0 || (double)p.n_theta * p.nx * p.ny >= 3.0e7;
+}
+
+/* One window, device-resident hit indices: exhaustive (run_window) or coarse-first. */
+int search_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p, const int32_t* col_dev,
+                  const int32_t* row_dev, csm_result* out_dev)
+{
+    ctx->last_nominal = (int64_t)p.n_theta * p.nx * p.ny;
+    ctx->last_coarse_nodes = 0;
+    ctx->last_fine_candidates = ctx->last_nominal;
+    ctx->tp_count_dev = nullptr;
+    if (!wants_two_phase(ctx, p))
+        return run_window(ctx, g, w, p, col_dev, row_dev, out_dev, nullptr);
+    int rc;
+    PhaseMap* pm = nullptr;
+    if ((rc = ensure_phase_map(ctx, g, w->coarse_level, std::max(p.nxc, p.nyc) + 1, &pm))) return rc;
+    /* the coarse window on the phase-major copy: candidate (xc, yc) = offsets (xc - wcx, yc - wcy) */
+    csm_window wc = *w;
+    wc.win_x = p.nxc / 2;
+    wc.win_y = p.nyc / 2;
+    wc.low_resolution = 1;
+    wc.coarse_level = 0;
+    Plan pc;
+    if ((rc = make_plan(ctx, *pm->grid, &wc, &pc))) return rc;
+    const size_t hn = (size_t)p.n_theta * p.n;
+    if ((rc = ensure(ctx, ctx->ph_hits, hn * 8 + 256))) return rc;
+    int32_t* pcol = reinterpret_cast<int32_t*>(ctx->ph_hits.p);
+    int32_t* prow = pcol + hn;
+    {
+        ScopedTimer tm(ctx, "project");
+        const int e = csm::launch_phase_hits(ctx->stream, col_dev, row_dev, hn, p.x_lo, p.y_lo, p.L, pm->hp, pm->wp,
+                                             pm->pad, ceil_div(g.rows, p.L), ceil_div(g.cols, p.L), wc.win_x, wc.win_y,
+                                             pcol, prow);
+        if (e)
+            return fail(ctx, CSM_EIO, "k_phase_hits launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    TwoPhaseCtl tp;
+    tp.mode = 1;
+    if ((rc = run_window(ctx, *pm->grid, &wc, pc, pcol, prow, nullptr, nullptr, false, &tp))) return rc;
+    tp.mode = 2;
+    if ((rc = run_window(ctx, g, w, p, col_dev, row_dev, out_dev, nullptr, false, &tp))) return rc;
+    ctx->last_coarse_nodes = (int64_t)p.n_theta * p.nxc * p.nyc;
+    ctx->last_fine_candidates = -1;         /* from the device counters, on request (csm_last_search_info) */
+    ctx->last_block_candidates = (int64_t)p.fine.cbx * p.fine.groups * p.fine.R;
+    return CSM_OK;
+}
 
 const uint32_t kTieCap = 1u << 16;
 const uint32_t kUncCap = 4096;
@@ -1681,6 +1924,7 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.two_slices = !(off & CSM_TUNE_NO_TWO_SLICES);
         t.joint = !(off & CSM_TUNE_NO_JOINT);
         t.bound_pass = !(off & CSM_TUNE_NO_BOUND_PASS);
+        t.two_phase = (off & CSM_TUNE_NO_TWO_PHASE) ? -1 : (off & CSM_TUNE_FORCE_TWO_PHASE) ? 1 : 0;
         t.tile_split = !(off & CSM_TUNE_NO_TILE_SPLIT);
         t.map_host_projection = (off & CSM_TUNE_MAP_HOST_PROJECTION) != 0;
         if (off & CSM_TUNE_NO_THETA_MAJOR)
@@ -1740,7 +1984,7 @@ int csm_destroy(csm_ctx* ctx)
     DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
-                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats, &ctx->b_items,
+                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats, &ctx->b_items, &ctx->tp_items, &ctx->ph_hits,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
                        &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs, &ctx->box_jobs,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
@@ -2297,7 +2541,7 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
                            dim3(kBlock), 0, ctx->stream, pj);
         HIP_TRY(ctx, hipGetLastError());
     }
-    if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
+    if ((rc = search_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
     /* ONE read-back and one wait per query (record + uncertified count); the exact paths run only
      * for a record that carries a tie or an edge-band flag */
     Tail tail;
@@ -2347,7 +2591,7 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
         if (patched) {
             HIP_TRY(ctx, hipMemcpy(col_dev, col.data(), hn * 4, hipMemcpyHostToDevice));
             HIP_TRY(ctx, hipMemcpy(row_dev, row.data(), hn * 4, hipMemcpyHostToDevice));
-            if ((rc = run_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, nullptr))) return rc;
+            if ((rc = search_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
             if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
             HIP_TRY(ctx, hipMemcpy(&out->raw, res_dev, sizeof(csm_result), hipMemcpyDeviceToHost));
         }
@@ -3644,6 +3888,27 @@ int csm_build_pyramids(csm_ctx* ctx, const uint64_t* map_ids, int32_t n_maps, co
 }
 
 /* ---- measurement hooks ---- */
+
+int csm_last_search_info(csm_ctx* ctx, csm_search_info* out)
+{
+    if (!ctx || !out)
+        return CSM_EINVAL;
+    std::memset(out, 0, sizeof(*out));
+    out->nominal_candidates = ctx->last_nominal;
+    out->coarse_nodes_scored = ctx->last_coarse_nodes;
+    out->fine_candidates_scored = ctx->last_fine_candidates;
+    if (ctx->tp_count_dev) {
+        uint32_t h[3] = { 0, 0, 0 };
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->tp_count_dev, 12, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        out->two_phase = 1;
+        out->blocks_scored = h[1];
+        out->blocks_skipped = h[2];
+        out->fine_candidates_scored = (int64_t)h[1] * ctx->last_block_candidates;
+    }
+    return CSM_OK;
+}
 
 int csm_bound_pass_stats(csm_ctx* ctx, uint64_t* blocks_scored, uint64_t* blocks_skipped)
 {

@@ -132,7 +132,10 @@ struct ScoreJob {
     uint16_t*  dump_k;         /* [n_theta][nx][ny] */
     uint32_t*  acc_s;          /* [n_theta][nx][ny] atomic accumulate (tile-split launches) */
     uint32_t*  acc_k;
-    int32_t    acc_x_major;    /* acc arrays laid out [n_theta][ny][nx] (coalesced atomics) */
+    int32_t    acc_x_major;    /* acc arrays laid out [n_theta][ny][nx] (coalesced atomics);
+                                  2: plain stores instead of atomic adds, [n_theta][nx][ny] (a launch in
+                                  which one lane computes a candidate's whole sum: the coarse pass of the
+                                  two-phase search) */
     uint32_t* in_s;            /* [n_theta][ny][nx]; non-null: no gathering, the sums are read from here (the
                                   arg-max pass after a tile-split launch) */
     uint32_t* in_k;            /* (the pass clears what it has read) */

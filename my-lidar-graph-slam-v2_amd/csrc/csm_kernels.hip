@@ -1356,6 +1356,24 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_pairs(ScoreJob job, int cbx
                                           (int)blockIdx.x, lane_map, BlockBase{ 0, 0, (int)gridDim.x });
 }
 
+/* The single-window fine kernel over a work list (two-phase search: only the candidate blocks whose
+ * coarse bound can still reach the best fine score; k_mark_blocks, csm_phase_kernels.hip): a fixed
+ * grid of workgroups takes the items i = blockIdx.x, blockIdx.x + gridDim.x, ... below *count;
+ * item = slice << 12 | candidate block. */
+template <int LS, int R, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock, 4) void k_score_pairs_list(ScoreJob job, int cbx, int groups, int ncb,
+                                                                const uint16_t* lane_map, const uint32_t* items,
+                                                                const uint32_t* count)
+{
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)*count);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[i]);
+        score_body_pairs<LS, R, WEIGHTED>(job, cbx, groups, 0, 1, (int)(it >> 12), (int)(it & 4095u), lane_map,
+                                          BlockBase{ 0, 0, ncb });
+        __syncthreads();
+    }
+}
+
 /* grid = (candidate blocks, theta slices, jobs) */
 template <int LS, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock, 4) void k_score_pairs_batch(const ScoreJob* jobs, int cbx, int groups,

@@ -109,7 +109,8 @@ __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S
     uint32_t* const acc_s = job.acc_s;
     uint32_t* const acc_k = job.acc_k;
     const int nx = job.nx, ny = job.ny, n_elig = job.n_elig, min_known = job.min_known;
-    const bool acc_x_major = job.acc_x_major != 0;
+    const bool acc_x_major = job.acc_x_major == 1;
+    const bool acc_store = job.acc_x_major == 2;
     const bool check_known = job.check_own_known != 0;
     const bool use_elig = !job.elig_only_if_band || (qflags & kFlagBandTouch);
     const bool band_touch = (block_best || tie_list) && n_elig > 0 && (*job.flags & kFlagBandTouch) != 0;
@@ -143,11 +144,16 @@ __device__ __forceinline__ void score_epilogue(const ScoreJob& job, uint32_t (&S
             if (acc_s) {
                 /* tile-split launch: slices add their partial integer sums.
                  * acc_x_major: consecutive lanes (dx) hit consecutive words */
-                const size_t ai = acc_x_major ? ((size_t)t * ny + yi) * nx + xi : ci;
-                if (S[r])
-                    atomicAdd(&acc_s[ai], S[r]);
-                if (K[r])
-                    atomicAdd(&acc_k[ai], K[r]);
+                if (acc_store) {
+                    acc_s[ci] = S[r];
+                    acc_k[ci] = K[r];
+                } else {
+                    const size_t ai = acc_x_major ? ((size_t)t * ny + yi) * nx + xi : ci;
+                    if (S[r])
+                        atomicAdd(&acc_s[ai], S[r]);
+                    if (K[r])
+                        atomicAdd(&acc_k[ai], K[r]);
+                }
             }
             if (!block_best && !tie_list)
                 continue;
