@@ -123,6 +123,7 @@ struct Tuning {
     bool joint = true;         /* ... on joint entry lists of the two slices (k_binj / k_score_joint_batch) */
     bool bound_pass = true;    /* ... preceded by the packed-fp32 bound pass; the exact kernel skips blocks that cannot win */
     int  two_phase = 0;        /* single large windows coarse-first: 0 by size, 1 always, -1 never */
+    bool graphs = true;        /* repeated single-query launch chains replayed as HIP graphs */
     bool tile_split = true;    /* small single windows: tile list split over blockIdx.z */
     bool map_host_projection = false;   /* map building: hit points on the host */
     int  theta_major = -1;     /* -1: by launch size */
@@ -142,6 +143,16 @@ struct csm_ctx {
     /* workspaces */
     DevBuf hits, sorted, tiles, ntiles, misc, coarse_s, coarse_k, best, dump_s, dump_k, scratch;
     DevBuf b_prod, b_hits, b_sorted, b_tiles, b_ntiles, b_lvl, b_best, b_jobs, b_out, b_abest, bound_stats, b_items, tp_items, ph_hits;
+    /* single-query launch chains as HIP graphs (csm_correlative_match): one per launch shape, keyed by
+     * everything that is baked into the nodes; alloc_epoch changes whenever a device buffer the
+     * nodes point at may have moved */
+    uint64_t alloc_epoch = 0;
+    bool capturing = false;
+    std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
+    std::map<std::vector<uint64_t>, int> graph_seen;
+    void* q_pin = nullptr;           /* pinned: [ProjJob | angles | ranges] up, [record | uncertified count] back */
+    size_t q_pin_cap = 0;
+    DevBuf q_dev;
     const uint32_t* tp_count_dev = nullptr;      /* [3] items / blocks kept / dropped of the last two-phase search */
     int64_t last_coarse_nodes = 0, last_fine_candidates = 0, last_nominal = 0, last_block_candidates = 0;   /* csm_last_search_info */
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
@@ -210,6 +221,9 @@ int ensure(csm_ctx* ctx, DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap)
         return CSM_OK;
+    if (ctx->capturing)
+        return fail(ctx, CSM_EIO, "internal: a workspace would grow during graph capture");
+    ++ctx->alloc_epoch;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (b.p)
         HIP_TRY(ctx, hipFree(b.p));
@@ -228,7 +242,7 @@ struct ScopedTimer {
     const char* name;
     ScopedTimer(csm_ctx* c, const char* n) : ctx(c), name(n)
     {
-        if (!ctx->timing ||
+        if (!ctx->timing || ctx->capturing ||
             (ctx->timing == 2 && std::strcmp(n, "score_fine") != 0 && std::strcmp(n, "score_bound") != 0))
             return;
         auto get = [&]() {
@@ -1182,6 +1196,7 @@ int build_level(csm_ctx* ctx, DeviceGrid& g, int win, Level* out, uint16_t* reus
     uint16_t* dst = reuse;
     size_t cap = reuse_cap;
     if (!dst) {
+        ++ctx->alloc_epoch;
         if (hipMalloc(reinterpret_cast<void**>(&dst), bytes) != hipSuccess)
             return fail(ctx, CSM_ENOMEM, "hipMalloc(%zu) failed", bytes);
         cap = bytes;
@@ -1247,6 +1262,7 @@ int ensure_xgrid(csm_ctx* ctx, DeviceGrid& g, int need_pad)
     const int xp = (g.cols + 2 * pad + 1) & ~1;
     const size_t bytes = (size_t)prows * xp * 8;
     if (bytes > g.xg_cap) {
+        ++ctx->alloc_epoch;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (g.xg)
             (void)hipFree(g.xg);
@@ -1369,14 +1385,20 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         }
     }
     uint32_t* flag_words = reinterpret_cast<uint32_t*>(ctx->misc.p);
-    if (!ctx->flags_ready) {
-        HIP_TRY(ctx, hipMemsetAsync(flag_words, 0, 8, ctx->stream));
+    if (!ctx->flags_ready && !ctx->capturing) {
+        HIP_TRY(ctx, hipMemsetAsync(flag_words, 0, 16, ctx->stream));
         ctx->flags_ready = true;
     }
     uint32_t* flags = flag_words + (ctx->flag_toggle & 1u);
     uint32_t* flags_next = flag_words + ((ctx->flag_toggle + 1u) & 1u);
-    if (tp_mode != 1)           /* the level pass sets no flag and has no finalize to clear one */
+    if (ctx->capturing) {
+        /* a graph bakes its pointers: a flag word of its own, cleared by a node of the graph */
+        flags = flag_words + 2;
+        flags_next = nullptr;
+        HIP_TRY(ctx, hipMemsetAsync(flags, 0, 4, ctx->stream));
+    } else if (tp_mode != 1) {  /* the level pass sets no flag and has no finalize to clear one */
         ctx->flag_toggle++;
+    }
 
     BinJob bj;
     std::memset(&bj, 0, sizeof(bj));
@@ -1925,6 +1947,7 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.joint = !(off & CSM_TUNE_NO_JOINT);
         t.bound_pass = !(off & CSM_TUNE_NO_BOUND_PASS);
         t.two_phase = (off & CSM_TUNE_NO_TWO_PHASE) ? -1 : (off & CSM_TUNE_FORCE_TWO_PHASE) ? 1 : 0;
+        t.graphs = !(off & CSM_TUNE_NO_GRAPHS);
         t.tile_split = !(off & CSM_TUNE_NO_TILE_SPLIT);
         t.map_host_projection = (off & CSM_TUNE_MAP_HOST_PROJECTION) != 0;
         if (off & CSM_TUNE_NO_THETA_MAJOR)
@@ -1979,12 +2002,18 @@ int csm_destroy(csm_ctx* ctx)
         return CSM_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->graphs)
+        (void)hipGraphExecDestroy(kv.second);
+    ctx->graphs.clear();
+    if (ctx->q_pin)
+        (void)hipHostFree(ctx->q_pin);
+    ctx->q_pin = nullptr;
     for (auto& kv : ctx->grids)
         free_levels(kv.second, false);
     DevBuf* bufs[] = { &ctx->hits, &ctx->sorted, &ctx->tiles, &ctx->ntiles, &ctx->misc,
                        &ctx->coarse_s, &ctx->coarse_k, &ctx->best, &ctx->dump_s, &ctx->dump_k,
                        &ctx->scratch, &ctx->b_prod, &ctx->b_hits, &ctx->b_sorted, &ctx->b_tiles,
-                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats, &ctx->b_items, &ctx->tp_items, &ctx->ph_hits,
+                       &ctx->b_ntiles, &ctx->b_lvl, &ctx->b_best, &ctx->b_jobs, &ctx->b_out, &ctx->b_abest, &ctx->bound_stats, &ctx->b_items, &ctx->tp_items, &ctx->ph_hits, &ctx->q_dev,
                        &ctx->fine_s, &ctx->fine_k, &ctx->tie, &ctx->ex_fine, &ctx->ex_fine_k, &ctx->ex_coarse, &ctx->ex_coarse_k,
                        &ctx->scan_dev, &ctx->unc, &ctx->sorted_rc, &ctx->b_sorted_rc, &ctx->rec_dev, &ctx->c_scans, &ctx->c_jobs, &ctx->box_jobs,
                        &ctx->m_rays, &ctx->m_recs, &ctx->m_cell, &ctx->m_lists, &ctx->m_cnt, &ctx->m_lut };
@@ -2495,7 +2524,6 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     Plan p;
     if ((rc = make_plan(ctx, *g, &w, &p))) return rc;
     if ((rc = ensure(ctx, ctx->hits, hn * 8 + 256))) return rc;
-    if ((rc = ensure(ctx, ctx->scan_dev, (size_t)n * 16))) return rc;
     if ((rc = ensure(ctx, ctx->unc, 16 + (size_t)kUncCap * 4))) return rc;
     int32_t* col_dev = reinterpret_cast<int32_t*>(ctx->hits.p);
     int32_t* row_dev = col_dev + hn;
@@ -2506,16 +2534,33 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     };
     Tail* tail_dev = reinterpret_cast<Tail*>(row_dev + hn);
     csm_result* res_dev = &tail_dev->res;
-    double* ang_dev = reinterpret_cast<double*>(ctx->scan_dev.p);
-    double* rng_dev = ang_dev + n;
     uint32_t* unc_count = &tail_dev->n_unc;
     uint32_t* unc_list = reinterpret_cast<uint32_t*>(ctx->unc.p) + 4;
-    /* angles and ranges in one upload */
-    ctx->stage.resize(2 * (size_t)n);
-    std::memcpy(ctx->stage.data(), scan->angles, (size_t)n * 8);
-    std::memcpy(ctx->stage.data() + n, scan->ranges, (size_t)n * 8);
-    HIP_TRY(ctx, hipMemcpyAsync(ang_dev, ctx->stage.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(unc_count, 0, 16, ctx->stream));
+    /* One query's stream work: [projection job | angles | ranges] up from a pinned block, the
+     * projection, the search, [record | uncertified count] back into the pinned block. The same
+     * sequence for every query of one launch shape, so from the third query of a shape on it is
+     * replayed as a HIP graph (one launch instead of nine; every varying input lives in the pinned
+     * block or in device memory the nodes point at). */
+    const size_t job_bytes = (sizeof(ProjJob) + 255) & ~(size_t)255;
+    const size_t up_bytes = job_bytes + (size_t)n * 16;
+    const size_t pin_bytes = up_bytes + 256;
+    if (pin_bytes > ctx->q_pin_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->q_pin)
+            (void)hipHostFree(ctx->q_pin);
+        ctx->q_pin = nullptr;
+        ctx->q_pin_cap = 0;
+        ++ctx->alloc_epoch;
+        if (hipHostMalloc(&ctx->q_pin, pin_bytes + pin_bytes / 4, hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, CSM_ENOMEM, "hipHostMalloc(%zu) failed", pin_bytes);
+        ctx->q_pin_cap = pin_bytes + pin_bytes / 4;
+    }
+    if ((rc = ensure(ctx, ctx->q_dev, up_bytes))) return rc;
+    char* pin = reinterpret_cast<char*>(ctx->q_pin);
+    char* qd = reinterpret_cast<char*>(ctx->q_dev.p);
+    double* ang_dev = reinterpret_cast<double*>(qd + job_bytes);
+    double* rng_dev = ang_dev + n;
+    Tail* tail_pin = reinterpret_cast<Tail*>(pin + ((up_bytes + 63) & ~(size_t)63));
     ProjJob pj;
     std::memset(&pj, 0, sizeof(pj));
     pj.angles = ang_dev;
@@ -2535,18 +2580,75 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
     pj.off_x = geom->offset_x;
     pj.off_y = geom->offset_y;
     pj.res = geom->resolution;
-    {
-        ScopedTimer tm(ctx, "project");
-        hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), proj_theta_groups(w.n_theta, ceil_div(n, kBlock))),
-                           dim3(kBlock), 0, ctx->stream, pj);
-        HIP_TRY(ctx, hipGetLastError());
+    std::memcpy(pin, &pj, sizeof(pj));
+    std::memcpy(pin + job_bytes, scan->angles, (size_t)n * 8);
+    std::memcpy(pin + job_bytes + (size_t)n * 8, scan->ranges, (size_t)n * 8);
+    const bool two_phase = wants_two_phase(ctx, p);
+    auto enqueue = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(qd, pin, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(unc_count, 0, 16, ctx->stream));
+        {
+            ScopedTimer tm(ctx, "project");
+            const int pb = ceil_div(n, kBlock);
+            hipLaunchKernelGGL(k_project_batch, dim3(pb, proj_theta_groups(w.n_theta, pb), 1), dim3(kBlock), 0,
+                               ctx->stream, reinterpret_cast<const ProjJob*>(qd));
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        int rc2 = search_window(ctx, *g, &w, p, col_dev, row_dev, res_dev);
+        if (rc2)
+            return rc2;
+        HIP_TRY(ctx, hipMemcpyAsync(tail_pin, tail_dev, sizeof(Tail), hipMemcpyDeviceToHost, ctx->stream));
+        return CSM_OK;
+    };
+    /* what a graph of this chain has baked in */
+    std::vector<uint64_t> key = {
+        ctx->alloc_epoch, (uint64_t)(uintptr_t)ctx->stream, (uint64_t)(uintptr_t)g->levels[0].cells,
+        (uint64_t)(uintptr_t)g->levels[level].cells, (uint64_t)(uintptr_t)g->xg, (uint64_t)g->xg_pad,
+        (uint64_t)g->rows, (uint64_t)g->cols, (uint64_t)g->known_r0, (uint64_t)g->known_c0,
+        (uint64_t)w.n_theta, (uint64_t)n, (uint64_t)w.win_x, (uint64_t)w.win_y, (uint64_t)w.low_resolution,
+        (uint64_t)(uint32_t)w.min_known, (uint64_t)w.merge_mode, 0 };
+    std::memcpy(&key.back(), &w.score_threshold, 8);
+    bool launched = false;
+    if (!two_phase && !ctx->timing && ctx->tune.graphs && !g->xg_stale) {
+        auto it = ctx->graphs.find(key);
+        if (it != ctx->graphs.end()) {
+            HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));
+            ctx->last_nominal = (int64_t)p.n_theta * p.nx * p.ny;
+            ctx->last_coarse_nodes = 0;
+            ctx->last_fine_candidates = ctx->last_nominal;
+            ctx->tp_count_dev = nullptr;
+            launched = true;
+        } else if (++ctx->graph_seen[key] >= 3) {
+            /* third query of this shape: every workspace has its size; record the chain */
+            if (ctx->graphs.size() >= 8) {
+                for (auto& kv : ctx->graphs)
+                    (void)hipGraphExecDestroy(kv.second);
+                ctx->graphs.clear();
+                ctx->graph_seen.clear();
+            }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                ctx->capturing = true;
+                const int rc_cap = enqueue();
+                ctx->capturing = false;
+                const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+                if (rc_cap == CSM_OK && e_end == hipSuccess && graph &&
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    ctx->graphs[key] = exec;
+                    HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
+                    launched = true;
+                }
+                if (graph)
+                    (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+            }
+        }
     }
-    if ((rc = search_window(ctx, *g, &w, p, col_dev, row_dev, res_dev))) return rc;
-    /* ONE read-back and one wait per query (record + uncertified count); the exact paths run only
-     * for a record that carries a tie or an edge-band flag */
-    Tail tail;
-    HIP_TRY(ctx, hipMemcpyAsync(&tail, tail_dev, sizeof(tail), hipMemcpyDeviceToHost, ctx->stream));
+    if (!launched && (rc = enqueue()))
+        return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    Tail tail = *tail_pin;
     {
         bool changed = false;
         if ((rc = resolve_window(ctx, *g, &w, p, col_dev, row_dev, res_dev, &tail.res, &changed))) return rc;

@@ -54,7 +54,10 @@ def test_default_line():
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     a = c["all_cores"]
     assert a["cores"] >= 1 and a["value"] > 0 and "OpenMP" in a["sample"]
-    cf = d["configs"]
+    assert "configs" not in d                   # the driver's parser keeps "config", not extra top-level keys
+    assert d["config"]["verified"] >= 8 and "fine_level" in d["config"]
+    cf = d["config"]["side_runs"]
+    assert set(d["config"]["side_runs_summary"]) == set(cf)
     assert cf["config2_single_query"]["latency_ms_median"] > 0
     c3 = cf["config3"]
     assert c3["value"] > 1e8 and c3["pyramid_build_ms"] > 0 and c3["end_to_end_value"] < c3["value"]
@@ -63,7 +66,21 @@ def test_default_line():
     c5 = cf["config5"]
     assert c5["candidates"] % (804 * 804) == 0 and c5["candidates"] > 9.2e8
     assert c5["value"] > 1e8 and c5["found"] == 1
-    _check_roofline(c5["roofline"])
+    ev = c5["evaluated"]
+    assert ev["coarse_nodes"] == c5["candidates"] // (804 * 804) * 201 * 201
+    assert 0 < ev["fine_candidates"] < c5["candidates"] // 4 and ev["fine_blocks_skipped"] > ev["fine_blocks_scored"]
+    r5 = c5["roofline"]
+    assert r5["bound"] == "lds" and 0 < r5["frac"] < 1 and abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-9
+
+
+@pytest.mark.parametrize("workload,steps", [("config5", "3"), ("latency", "200")])
+def test_side_workloads_as_lines_of_their_own(workload, steps):
+    d = _run("--workload", workload, "--steps", steps, "--warmup", "1")
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == int(steps) and d["value"] > 1e8
+    assert d["config"]["workload"].startswith("configs[4]" if workload == "config5" else "configs[1]")
+    assert d["roofline"]["bound"] == "lds" and 0 < d["roofline"]["frac"] < 1
 
 
 @pytest.mark.parametrize("workload", ["loop", "map"])
