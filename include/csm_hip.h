@@ -76,7 +76,6 @@ typedef struct csm_ctx csm_ctx;
 #define CSM_TUNE_NO_TWO_PHASE      512u   /* single windows are always searched exhaustively */
 #define CSM_TUNE_FORCE_TWO_PHASE  1024u   /* ... always coarse-first (default: by window size) */
 #define CSM_TUNE_NO_GRAPHS        2048u   /* single queries are always launched kernel by kernel */
-#define CSM_TUNE_NO_BOUND_ONE_BLOCK 4096u /* bound pass in the exact kernel's row blocks (R = 8 + R = 6) */
 
 typedef struct {
     int32_t  device_id;          /* HIP device ordinal */

@@ -37,7 +37,7 @@ class Config(C.Structure):
 TUNE_NO_LANE_MAP, TUNE_NO_XCD_MAP, TUNE_NO_PAIR_TAIL, TUNE_NO_TWO_SLICES = 1, 2, 4, 8
 TUNE_NO_THETA_MAJOR, TUNE_NO_TILE_SPLIT, TUNE_MAP_HOST_PROJECTION, TUNE_NO_JOINT = 16, 32, 64, 128
 TUNE_NO_BOUND_PASS = 256
-TUNE_NO_TWO_PHASE, TUNE_FORCE_TWO_PHASE, TUNE_NO_GRAPHS, TUNE_NO_BOUND_ONE_BLOCK = 512, 1024, 2048, 4096
+TUNE_NO_TWO_PHASE, TUNE_FORCE_TWO_PHASE, TUNE_NO_GRAPHS = 512, 1024, 2048
 GROUP_FORCE_RCCL = 1
 
 

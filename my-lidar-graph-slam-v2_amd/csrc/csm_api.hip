@@ -124,7 +124,6 @@ struct Tuning {
     bool bound_pass = true;    /* ... preceded by the packed-fp32 bound pass; the exact kernel skips blocks that cannot win */
     int  two_phase = 0;        /* single large windows coarse-first: 0 by size, 1 always, -1 never */
     bool graphs = true;        /* repeated single-query launch chains replayed as HIP graphs */
-    bool bound_one_block = true;   /* bound pass: the window's rows in one block of R = 14 rows per lane (32-row tiles) */
     bool tile_split = true;    /* small single windows: tile list split over blockIdx.z */
     bool map_host_projection = false;   /* map building: hit points on the host */
     int  theta_major = -1;     /* -1: by launch size */
@@ -422,10 +421,6 @@ struct PassPlan {
     int lists = 1;            /* entry lists in LDS: 2 = the batch kernel that takes two slices per workgroup */
     bool joint = false;       /* ... on joint entries of the two slices (one list; csm_joint_kernels.hip) */
     bool fp32 = false;        /* this launch is the packed-fp32 bound pass of the joint kernel */
-    int yb_rows = 0;          /* ... with all rows in one block (R = 14): rows of the exact kernel's row blocks */
-    int tile_h = 0;           /* rows of the joint lists' endpoint tiles (0 = kTile) */
-    int ncb_total = 0;        /* candidate blocks of the window in the EXACT plan's numbering (the
-                                 one-block bound pass writes its maxima in that numbering) */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -514,9 +509,9 @@ bool plan_pass(const Tuning& tune, int nx, int ny, int stride, PassPlan* out)
  * tail block of the frontend window). */
 const int kPairLS[] = { 86, 98, 118, 124, 130, 150, 156, 162, 182 };
 
-size_t pair_lds_bytes(int ls, int cby, int lists, int tile_h = kTile)
+size_t pair_lds_bytes(int ls, int cby, int lists)
 {
-    const size_t region = (size_t)((tile_h + cby) / 2 + 1) * ls * 8;
+    const size_t region = (size_t)((kTile + cby) / 2 + 1) * ls * 8;
     return ((region + 1023) / 1024) * 1024 + (size_t)lists * kPbMax * 4;
 }
 
@@ -635,7 +630,7 @@ int pick_buffers(const Tuning& tune, size_t lds_one, long blocks)
 size_t pass_lds_bytes(const PassPlan& p)
 {
     if (p.pairs)
-        return pair_lds_bytes(p.lstride, p.groups * p.R, p.lists, p.tile_h ? p.tile_h : kTile);
+        return pair_lds_bytes(p.lstride, p.groups * p.R, p.lists);
     const int cby = p.groups * p.R;
     const int rows = p.stride > 1 ? ((kTile + p.stride - 1) / p.stride + cby - 1) * p.stride
                                   : kTile + cby - 1;
@@ -1046,7 +1041,6 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
         L.cb_base = bb.cb_base;
         L.ncb = bb.ncb;
         L.fp32 = pp.fp32 ? 1 : 0;
-        L.yb_rows = pp.yb_rows;
         if (list && !pp.fp32) {
             L.items = list->items[which];
             L.item_count = list->counts + which;
@@ -1081,8 +1075,7 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
          * multiply-adds per entry for half of the workgroups (CSM_TUNE_NO_PAIR_TAIL: one launch). */
         const int cby = pp.groups * pp.R;
         if (!tail_split(ctx, pp))
-            return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb_total ? pp.ncb_total : pp.ncb() },
-                                      list, 0);
+            return launch_pairs_batch(ctx, jobs_dev, pp, grid, BlockBase{ 0, 0, pp.ncb() }, list, 0);
         PassPlan tail = pp;
         tail.R = 6;
         /* The tail launch keeps the main launch's row pitch: k_bin wrote the entries' LDS offsets
@@ -1955,7 +1948,6 @@ int csm_create(const csm_config* cfg, csm_ctx** out)
         t.bound_pass = !(off & CSM_TUNE_NO_BOUND_PASS);
         t.two_phase = (off & CSM_TUNE_NO_TWO_PHASE) ? -1 : (off & CSM_TUNE_FORCE_TWO_PHASE) ? 1 : 0;
         t.graphs = !(off & CSM_TUNE_NO_GRAPHS);
-        t.bound_one_block = !(off & CSM_TUNE_NO_BOUND_ONE_BLOCK);
         t.tile_split = !(off & CSM_TUNE_NO_TILE_SPLIT);
         t.map_host_projection = (off & CSM_TUNE_MAP_HOST_PROJECTION) != 0;
         if (off & CSM_TUNE_NO_THETA_MAJOR)
@@ -3009,40 +3001,6 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     for (int k = 0; k < nq && bound_pass; ++k)
         bound_pass = (resident ? resident->windows[idx[k]].min_known
                                : csm_host_min_known(pp[k].n, spec.known_thr)) <= 1;
-    /* The bound pass takes the window's rows in ONE block where 14 rows per lane cover them with the
-     * exact plan's column blocks (84 rows: 6 lane groups x 14): the per-(block, tile) costs -- window
-     * copy, barriers, float table, entry decode -- are paid once instead of once per row block, and a
-     * lane reads 8 row pairs for 14 rows instead of 5 + 4 for 8 + 6. Its LDS region must hold tile +
-     * window rows, so the joint lists are then binned in endpoint tiles of 32 rows. */
-    PassPlan bound_plan = lp[0];
-    bound_plan.fp32 = true;
-    const int ncb_exact = lp[0].ncb();
-    int tile_h = 0;
-    if (bound_pass && ctx->tune.bound_one_block) {
-        const int g14 = ceil_div(ny, 14);
-        const int exact_cby = lp[0].groups * lp[0].R;
-        size_t binj32 = 0;
-        for (int k = 0; k < nq; ++k)
-            binj32 = std::max(binj32, csm::binj_lds_bytes(pp[k].tiles_x * 2 * pp[k].tiles_y + pp[k].tiles_x, pp[k].n,
-                                                          bin_hash_size(2 * pp[k].n)));
-        if (g14 * lp[0].cbx <= kBlock && ceil_div(ny, exact_cby) <= 2 && 32 + g14 * 14 <= kTile + kPairMaxCby &&
-            pair_lds_bytes(lp[0].lstride, g14 * 14, 2, 32) <= 80 * 1024 - 1024 && binj32 <= 78 * 1024) {
-            bound_plan.R = 14;
-            bound_plan.groups = g14;
-            bound_plan.ncby = 1;
-            bound_plan.yb_rows = lp[0].ncby > 1 ? exact_cby : 0;
-            bound_plan.ncb_total = ncb_exact;
-            tile_h = 32;
-            bound_plan.tile_h = tile_h;
-            lp[0].tile_h = tile_h;
-        }
-    }
-    if (tile_h)
-        for (int k = 0; k < nq; ++k) {
-            pp[k].tiles_y = ceil_div(pp[k].grid->rows + pp[k].win_y + (-pp[k].win_y + pp[k].ny - 1) + 1, tile_h);
-            binj_lds = std::max(binj_lds, csm::binj_lds_bytes(pp[k].tiles_x * pp[k].tiles_y, pp[k].n,
-                                                              bin_hash_size(2 * pp[k].n)));
-        }
     for (int k = 0; k < nq; ++k) {
         BatchPrep& p = pp[k];
         /* lists and records per slice, or per pair of slices (2 n entries each) */
@@ -3245,7 +3203,6 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
         B.pair_mode = joint ? 2 : lp[0].pairs ? 1 : 0;
-        B.tile_h = joint ? tile_h : 0;
 #ifdef CSM_BIN_TIMING
         B.tuning_counters = bin_debug_buffer();
 #endif
@@ -3273,7 +3230,6 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         base.flags = d_flags + k;
         base.min_known = min_known;
         base.joint = joint ? 1 : 0;
-        base.tile_h = joint ? tile_h : 0;
         base.rank_l = spec.bnb ? 1 : spec.unit;
         for (int h = 1; h <= H; ++h) {
             ScoreJob& S = sj[h][k];
@@ -3459,8 +3415,10 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
             return rc;
     }
     if (bound_pass) {
+        PassPlan fp = lp[0];
+        fp.fp32 = true;
         ScopedTimer tm(ctx, "score_bound");
-        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, bound_plan, n_theta_max, 1)))
+        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, fp, n_theta_max, 1)))
             return rc;
     }
     if (bound_pass) {

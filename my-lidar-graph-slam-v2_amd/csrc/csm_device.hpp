@@ -67,8 +67,7 @@ struct BinJob {
     uint32_t* flags;           /* [1] CSM_FLAG_* accumulated with atomicOr */
     uint32_t* reserved_ptr;    /* unused (round 1 cleared the coarse accumulators here) */
     uint32_t* tuning_counters; /* CSM_BIN_TIMING builds: per-workgroup phase cycles; else null */
-    int32_t   tile_h;          /* joint mode: rows of an endpoint tile (0 = kTile; 32 when the bound pass takes
-                                  the whole candidate window in one row block: its LDS region holds tile + window rows) */
+    int32_t   reserved_words;
     int32_t n_theta, n_points, max_tiles;
     int32_t rows, cols;
     int32_t x_lo, y_lo;        /* most negative candidate offset */
@@ -171,7 +170,7 @@ struct ScoreJob {
     float* approx_best;
     float* dump_f;             /* optional [n_theta][nx][ny]: every candidate's fp32 key (tests) */
     float approx_slack;
-    int32_t tile_h;            /* rows of an endpoint tile of the joint lists (0 = kTile) */
+    int32_t pad1;
     uint32_t* bound_stats;     /* optional [2]: blocks the exact kernel scored / skipped after the bound pass */
 };
 

@@ -24,8 +24,6 @@ struct JointLaunch {
     int xcd_map;
     int row_base, cb_base, ncb; /* BlockBase: where this launch sits among the window's row blocks */
     int fp32;                   /* 1: the packed-fp32 bound pass (k_score_jointf_batch) */
-    int yb_rows = 0;            /* bound pass with R = 14 (one row block per window): rows of the exact
-                                   kernel's row blocks, for the per-exact-block maxima */
     /* exact kernel over a work list (k_score_joint_list) instead of the grid: items / item_count
      * as k_bound_select wrote them, list_blocks workgroups share them */
     const uint32_t* items = nullptr;

@@ -63,7 +63,6 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
         return;
     const int n = uni(job.n_points);
     const int n2 = t0 + 1 < n_theta_job ? 2 * n : n;         /* beams of this pair */
-    const uint32_t th = (uint32_t)(uni(job.tile_h) ? uni(job.tile_h) : kTile);      /* tile rows (columns: kTile) */
     const int ntp = (ntile + 1) & ~1;
     unsigned long long* rowmask = reinterpret_cast<unsigned long long*>(sm_binj);      /* [ntp] */
     unsigned long long* colmask = rowmask + ntp;                                       /* [ntp] */
@@ -147,8 +146,8 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
             bool odd = false;
             uint32_t cmp = 0xffffffffu;
             if (valid) {
-                const uint32_t tile = ((uint32_t)rr / th) * (uint32_t)tiles_x + (uint32_t)cc / kTile;
-                const uint32_t rb = (uint32_t)rr % th, cb = (uint32_t)cc % kTile;
+                const uint32_t tile = ((uint32_t)rr / kTile) * (uint32_t)tiles_x + (uint32_t)cc / kTile;
+                const uint32_t rb = (uint32_t)rr % kTile, cb = (uint32_t)cc % kTile;
                 key[u] = ((tile << 12) | ((rb >> 1) << 6) | cb) + 1u;
                 odd = (rb & 1u) != 0;
                 cmp = key[u] | (sl << 31);                     /* a run never spans the two slices */
@@ -285,7 +284,7 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
             const int rmin = rlo & ~1;
             for (uint32_t done = 0; done < c; done += kJRec) {
                 TileRec rec;
-                rec.r0 = (i / tiles_x) * (int)th - y_hi - fs + rmin;
+                rec.r0 = (i / tiles_x) * kTile - y_hi - fs + rmin;
                 rec.c0 = (i % tiles_x) * kTile - x_hi + clo;
                 rec.start = off + done;
                 rec.count = min(c - done, (uint32_t)kJRec);
@@ -543,7 +542,7 @@ __device__ __forceinline__ void score_body_joint(const ScoreJob& job, int cbx, i
     const int x0 = job.x_lo + bx * cbx;
     const int y0 = job.y_lo + row0;
     constexpr int kRowBytes = LS * 8;
-    const int prows_full = ((job.tile_h ? job.tile_h : kTile) + cby) / 2 + 1;
+    const int prows_full = (kTile + cby) / 2 + 1;
     const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb = sm_cells + max_pieces * 256;
@@ -666,7 +665,7 @@ __device__ __forceinline__ void joint_fmads(uint32_t w, const unsigned long long
                                             unsigned long long fb, f32x2 (&ea)[R / 2], f32x2 (&oa)[R / 2 + 1],
                                             f32x2 (&eb)[R / 2], f32x2 (&ob)[R / 2 + 1])
 {
-    static_assert(R == 6 || R == 8, "rows per lane (R = 14: joint_fmads14)");
+    static_assert(R == 6 || R == 8, "rows per lane");
     uint32_t m;
     if constexpr (R == 8) {
         asm("s_bfe_u32 %[m], %[w], 0x40010\n\t"
@@ -719,33 +718,6 @@ __device__ __forceinline__ void joint_fmads(uint32_t w, const unsigned long long
             : "scc");
     }
 }
-/* R = 14 (the whole 84-row window in one row block): 7 + 8 accumulator pairs per slice exceed one
- * asm statement's operand limit for two slices, so one statement per slice. BIT: where the slice's
- * even-row count sits in the entry word (the odd-row count 4 bits above). */
-template <int BIT>
-__device__ __forceinline__ void joint_fmads14(uint32_t w, const unsigned long long (&q)[8], unsigned long long f,
-                                              f32x2 (&e)[7], f32x2 (&o)[8])
-{
-    uint32_t m;
-    asm("s_bfe_u32 %[m], %[w], %[sel_e]\n\t"
-        "s_cbranch_scc0 1f\n\t"
-        CSM_JFMA_E(e0, q0, f) CSM_JFMA_E(e1, q1, f) CSM_JFMA_E(e2, q2, f) CSM_JFMA_E(e3, q3, f)
-        CSM_JFMA_E(e4, q4, f) CSM_JFMA_E(e5, q5, f) CSM_JFMA_E(e6, q6, f)
-        "1:\n\t"
-        "s_bfe_u32 %[m], %[w], %[sel_o]\n\t"
-        "s_cbranch_scc0 2f\n\t"
-        CSM_JFMA_O(o0, q0, f) CSM_JFMA_O(o1, q1, f) CSM_JFMA_O(o2, q2, f) CSM_JFMA_O(o3, q3, f)
-        CSM_JFMA_O(o4, q4, f) CSM_JFMA_O(o5, q5, f) CSM_JFMA_O(o6, q6, f) CSM_JFMA_O(o7, q7, f)
-        "2:"
-        : [m] "=&s"(m), [e0] "+v"(e[0]), [e1] "+v"(e[1]), [e2] "+v"(e[2]), [e3] "+v"(e[3]), [e4] "+v"(e[4]),
-          [e5] "+v"(e[5]), [e6] "+v"(e[6]), [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]),
-          [o4] "+v"(o[4]), [o5] "+v"(o[5]), [o6] "+v"(o[6]), [o7] "+v"(o[7])
-        : [w] "s"(w), [sel_e] "n"((4 << 16) | BIT), [sel_o] "n"((4 << 16) | (BIT + 4)), [q0] "v"(q[0]),
-          [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [q4] "v"(q[4]), [q5] "v"(q[5]), [q6] "v"(q[6]),
-          [q7] "v"(q[7]), [f] "v"(f)
-        : "scc");
-}
-
 #undef CSM_JFMA_E
 #undef CSM_JFMA_O
 
@@ -766,31 +738,16 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
         lds_read_b64<1 * kRowBytes>(addr, q[1]);
         lds_read_b64<2 * kRowBytes>(addr, q[2]);
         lds_read_b64<3 * kRowBytes>(addr, q[3]);
-        if constexpr (R >= 8)
+        if (R >= 8)
             lds_read_b64<4 * kRowBytes>(addr, q[4]);
-        if constexpr (R >= 14) {
-            lds_read_b64<5 * kRowBytes>(addr, q[5]);
-            lds_read_b64<6 * kRowBytes>(addr, q[6]);
-            lds_read_b64<7 * kRowBytes>(addr, q[7]);
-        }
         lds_read_b64<0>(faddr, f[0]);
         lds_read_b64<8>(faddr, f[1]);
-    };
-    auto mads = [&](uint32_t w, const unsigned long long (&q)[NQ], const unsigned long long (&f)[2]) {
-        if constexpr (R == 14) {
-            joint_fmads14<16>(w, q, f[0], ea, oa);
-            joint_fmads14<24>(w, q, f[1], eb, ob);
-        } else {
-            joint_fmads<R>(w, q, f[0], f[1], ea, oa, eb, ob);
-        }
     };
     /* waits until all but the `LATER` youngest LDS reads have landed; ties every register the
      * mads are about to read */
     auto wait = [&](auto later, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
         constexpr int LATER = decltype(later)::value;
-        if constexpr (R >= 14)
-            asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(f[0]), "+v"(f[1]) : "n"(LATER));
-        else if constexpr (R >= 8)
+        if constexpr (R >= 8)
             asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(f[0]), "+v"(f[1]) : "n"(LATER));
         else
             asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(f[0]), "+v"(f[1]) : "n"(LATER));
@@ -811,22 +768,22 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
             issue(o0, fbase, qa, fa);
             issue(o1, fbase + 16u, qb, fb);
             wait(later_t(), qa, fa);
-            mads(o0, qa, fa);
+            joint_fmads<R>(o0, qa, fa[0], fa[1], ea, oa, eb, ob);
             issue(o2, fbase + 32u, qc, fc);
             wait(later_t(), qb, fb);
-            mads(o1, qb, fb);
+            joint_fmads<R>(o1, qb, fb[0], fb[1], ea, oa, eb, ob);
             issue(o3, fbase + 48u, qd, fd);
             wait(later_t(), qc, fc);
-            mads(o2, qc, fc);
+            joint_fmads<R>(o2, qc, fc[0], fc[1], ea, oa, eb, ob);
             wait(now_t(), qd, fd);
-            mads(o3, qd, fd);
+            joint_fmads<R>(o3, qd, fd[0], fd[1], ea, oa, eb, ob);
         }
         for (; j < stop; ++j) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
             unsigned long long qa[NQ], fa[2];
             issue(o, ftab_addr + (uint32_t)j * 16u, qa, fa);
             wait(now_t(), qa, fa);
-            mads(o, qa, fa);
+            joint_fmads<R>(o, qa, fa[0], fa[1], ea, oa, eb, ob);
         }
         if ((j & 63) == 0 && j < cnt)
             pb_cur = lpb[j + lane];
@@ -835,16 +792,13 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
 
 /* Workgroup = (pair of theta slices, candidate block), as score_body_joint; writes
  * approx_best[t][block] = greatest fp32 key among the block's candidates of slice t (0 if none). */
-/* yb_rows > 0: the exact kernel's row blocks are yb_rows candidate rows tall (its last one takes the
- * rest) while this launch takes the window's rows in ONE block (R = 14): the maxima are kept per exact
- * row block -- a block of this launch spans at most two of them. */
 template <int LS, int R>
 __device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, int groups, const uint16_t* lane_map,
-                                                  int bid_x, int bid_y, BlockBase bb, int yb_rows)
+                                                  int bid_x, int bid_y, BlockBase bb)
 {
     static_assert(R % 2 == 0 && LS % 2 == 0, "pair rows, 16-byte rows");
     extern __shared__ __attribute__((aligned(16))) uint16_t sm_tile[];
-    __shared__ float red[4][kBlock / 64];
+    __shared__ float red[2][kBlock / 64];
     const int t0 = 2 * bid_y, t1 = t0 + 1;
     const int n_theta = __builtin_amdgcn_readfirstlane(job.n_theta);
     if (t0 >= n_theta || !job.approx_best)
@@ -869,7 +823,7 @@ __device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, 
     const int x0 = job.x_lo + bx * cbx;
     const int y0 = job.y_lo + row0;
     constexpr int kRowBytes = LS * 8;
-    const int prows_full = ((job.tile_h ? job.tile_h : kTile) + cby) / 2 + 1;
+    const int prows_full = (kTile + cby) / 2 + 1;
     const int max_pieces = (prows_full * kRowBytes + 1023) >> 10;
     uint32_t* sm_cells = reinterpret_cast<uint32_t*>(sm_tile);
     uint32_t* lpb = sm_cells + max_pieces * 256;                 /* [kJRec] entry words */
@@ -949,11 +903,8 @@ __device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, 
 
     /* this lane's candidates: column bx * cbx + dxi, rows row0 + g * R + r */
     const int xi = bx * cbx + dxi;
-    /* best[slice][which of the (at most two) exact row blocks this block spans] */
-    float b00 = 0.f, b01 = 0.f, b10 = 0.f, b11 = 0.f;
+    float best0 = 0.f, best1 = 0.f;
     float* const dump_f = job.dump_f;
-    const int n_yb = yb_rows > 0 ? (job.ny + yb_rows - 1) / yb_rows : 1;
-    const int yb0 = yb_rows > 0 ? min(row0 / yb_rows, n_yb - 1) : 0;
     if (lane_on && xi < job.nx) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -962,14 +913,8 @@ __device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, 
                 continue;
             const float w0 = (r & 1 ? ea[r / 2].y + oa[(r + 1) / 2].x : ea[r / 2].x + oa[r / 2].y);
             const float w1 = (r & 1 ? eb[r / 2].y + ob[(r + 1) / 2].x : eb[r / 2].x + ob[r / 2].y);
-            const bool second = yb_rows > 0 && min(yi / yb_rows, n_yb - 1) != yb0;
-            if (second) {
-                b01 = fmaxf(b01, w0);
-                b11 = fmaxf(b11, w1);
-            } else {
-                b00 = fmaxf(b00, w0);
-                b10 = fmaxf(b10, w1);
-            }
+            best0 = fmaxf(best0, w0);
+            best1 = fmaxf(best1, w1);
             if (dump_f) {
                 dump_f[((size_t)t0 * job.nx + xi) * job.ny + yi] = w0;
                 if (two)
@@ -979,54 +924,33 @@ __device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, 
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        b00 = fmaxf(b00, __shfl_xor(b00, m, 64));
-        b01 = fmaxf(b01, __shfl_xor(b01, m, 64));
-        b10 = fmaxf(b10, __shfl_xor(b10, m, 64));
-        b11 = fmaxf(b11, __shfl_xor(b11, m, 64));
+        best0 = fmaxf(best0, __shfl_xor(best0, m, 64));
+        best1 = fmaxf(best1, __shfl_xor(best1, m, 64));
     }
     if (lane == 0) {
-        red[0][wave] = b00;
-        red[1][wave] = b01;
-        red[2][wave] = b10;
-        red[3][wave] = b11;
+        red[0][wave] = best0;
+        red[1][wave] = best1;
     }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < kBlock / 64; ++w) {
-            b00 = fmaxf(b00, red[0][w]);
-            b01 = fmaxf(b01, red[1][w]);
-            b10 = fmaxf(b10, red[2][w]);
-            b11 = fmaxf(b11, red[3][w]);
+            best0 = fmaxf(best0, red[0][w]);
+            best1 = fmaxf(best1, red[1][w]);
         }
-        if (yb_rows > 0) {
-            /* exact block of (row block yb, column block bx) = yb * ncbx + bx */
-            const size_t c0 = (size_t)yb0 * ncbx + bx, c1 = c0 + ncbx;
-            const bool has1 = yb0 + 1 < n_yb && (row0 + cby > (yb0 + 1) * yb_rows);
-            job.approx_best[(size_t)t0 * bb.ncb + c0] = b00;
-            if (has1)
-                job.approx_best[(size_t)t0 * bb.ncb + c1] = b01;
-            if (two) {
-                job.approx_best[(size_t)t1 * bb.ncb + c0] = b10;
-                if (has1)
-                    job.approx_best[(size_t)t1 * bb.ncb + c1] = b11;
-            }
-        } else {
-            const int cbg = bid_x + bb.cb_base;
-            job.approx_best[(size_t)t0 * bb.ncb + cbg] = b00;
-            if (two)
-                job.approx_best[(size_t)t1 * bb.ncb + cbg] = b10;
-        }
+        const int cbg = bid_x + bb.cb_base;
+        job.approx_best[(size_t)t0 * bb.ncb + cbg] = best0;
+        if (two)
+            job.approx_best[(size_t)t1 * bb.ncb + cbg] = best1;
     }
 }
 
 template <int LS, int R>
 __global__ __launch_bounds__(kBlock, 4) void k_score_jointf_batch(const ScoreJob* jobs, int cbx, int groups,
-                                                                  const uint16_t* lane_map, int xcd_map, BlockBase bb,
-                                                                  int yb_rows)
+                                                                  const uint16_t* lane_map, int xcd_map, BlockBase bb)
 {
     int bx, by, bz;
     xcd_block(xcd_map, bx, by, bz);
-    score_body_jointf<LS, R>(jobs[bz], cbx, groups, lane_map, bx, by, bb, yb_rows);
+    score_body_jointf<LS, R>(jobs[bz], cbx, groups, lane_map, bx, by, bb);
 }
 
 /* grid = (candidate blocks, ceil(theta slices / 2), jobs) */
@@ -1160,18 +1084,6 @@ hipError_t grant_lds(int device, const void* fn, size_t bytes)
 }
 
 template <int LS, int R>
-hipError_t launch_jointf(const csm::JointLaunch& L)
-{
-    auto kernel = csm::k_score_jointf_batch<LS, R>;
-    const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(kernel), L.lds_bytes);
-    if (e != hipSuccess)
-        return e;
-    hipLaunchKernelGGL(kernel, L.grid, dim3(csm::kBlock), L.lds_bytes, L.stream, L.jobs_dev, L.cbx, L.groups,
-                       L.lane_map, L.xcd_map, csm::BlockBase{ L.row_base, L.cb_base, L.ncb }, L.yb_rows);
-    return hipGetLastError();
-}
-
-template <int LS, int R>
 hipError_t launch_joint(const csm::JointLaunch& L)
 {
     if (L.items) {
@@ -1184,9 +1096,7 @@ hipError_t launch_joint(const csm::JointLaunch& L)
                            L.item_count);
         return hipGetLastError();
     }
-    if (L.fp32)
-        return launch_jointf<LS, R>(L);
-    auto kernel = csm::k_score_joint_batch<LS, R>;
+    auto kernel = L.fp32 ? csm::k_score_jointf_batch<LS, R> : csm::k_score_joint_batch<LS, R>;
     const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(kernel), L.lds_bytes);
     if (e != hipSuccess)
         return e;
@@ -1216,8 +1126,6 @@ int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, in
 }
 
 #define JOINT_CASE(LS)                                                                 \
-    if (L.ls == LS && L.R == 14 && L.fp32)                                             \
-        return (int)launch_jointf<LS, 14>(L);                                          \
     if (L.ls == LS && L.R == 8)                                                        \
         return (int)launch_joint<LS, 8>(L);                                            \
     if (L.ls == LS && L.R == 6)                                                        \

@@ -46,8 +46,7 @@ def headline(oracle):
     return wl, lits, dumps
 
 
-VARIANTS = [("default", 0), ("no_bound_pass", L.TUNE_NO_BOUND_PASS), ("bound_in_row_blocks", L.TUNE_NO_BOUND_ONE_BLOCK),
-            ("no_pair_tail", L.TUNE_NO_PAIR_TAIL),
+VARIANTS = [("default", 0), ("no_bound_pass", L.TUNE_NO_BOUND_PASS), ("no_pair_tail", L.TUNE_NO_PAIR_TAIL),
             ("no_lane_map", L.TUNE_NO_LANE_MAP), ("no_xcd_map", L.TUNE_NO_XCD_MAP), ("no_joint", L.TUNE_NO_JOINT),
             ("one_slice", L.TUNE_NO_TWO_SLICES | L.TUNE_NO_JOINT),
             ("all_off", L.TUNE_NO_PAIR_TAIL | L.TUNE_NO_LANE_MAP | L.TUNE_NO_XCD_MAP | L.TUNE_NO_JOINT)]
