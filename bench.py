@@ -53,7 +53,7 @@ LDS_PEAK_GBS = 256.0 * 256 * 2.4
 METRIC = "candidate poses scored/sec (CSM+BnB), 1/2/4/8 GPU; % HBM roofline"
 N_BEAMS = 1080
 LOOP_PARAMS = (2.5, 2.5, 0.5, 2, 0.55, 0.6)    # launcher_settings_default.json:130-131, 143-146
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_fine_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_fine_traffic.json")
 
 
 def make_workload(rank, n_scans):
@@ -506,7 +506,9 @@ def measure_config5(dev_index, runs=2, warmup=1):
             "kernel_us_per_query": kern,
             "roofline": {"bound": "lds", "kernel": dom, "unit": "GB/s", "peak": LDS_PEAK_GBS,
                          "achieved": ach, "frac": ach / LDS_PEAK_GBS if ach else None,
-                         "avg_launch_us": dom_us, "traffic": None,
+                         "avg_launch_us": dom_us,
+                         "traffic": pmc_traffic(os.path.join(ROOT, "profiles", "r03_config5_pmc_traffic.json"))[0],
+                         "traffic_source": pmc_traffic(os.path.join(ROOT, "profiles", "r03_config5_pmc_traffic.json"))[1],
                          "note": "LDS gather bytes (4 B x cell entries x candidates the kernel scores) / its time; "
                                  "HBM-side traffic of this workload: profiles/ (PMC passes)"}}
 
@@ -761,6 +763,159 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
         tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if rank == 0:
+        line = {
+            "metric": "map cell updates/sec (latest-map build + match per step)",
+            "value": info["cell_updates"] * args.steps * world / dt, "unit": "cell updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "frontend cycle: ConstructMapFromScans of 10 x 1080 beams (%d x %d cells, "
+                                   "%d rays, %d cell updates) + ScanMatcherCorrelative on the resident map; "
+                                   "host-inclusive calls" % (shape["rows"], shape["cols"], info["rays"],
+                                                             info["cell_updates"]),
+                       "map_kernels_us_per_step": build_ms / max(1, build_n) * 1e3,
+                       "build_ms_per_step": split_timed[0],
+                       "match_ms_per_step": split_timed[1],
+                       "match_kernels_us": {k: ctx.kernel_time(k)[0] / k_steps * 1e3 for k in
+                                            ("boxmax", "project", "bin", "score_coarse", "score_fine",
+                                             "finalize")},
+                       "match_found": out["pose_found"], "match_flags": out["raw"]["flags"],
+                       "match_tie_count": out["raw"]["tie_count"],
+                       "match_setup_us": out["input_setup_us"], "match_optimization_us": out["optimization_us"],
+                       "parallelism": "independent replicas" if world > 1 else "single GPU"},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 5.0:
+                oracle.construct_map(mc["shape"], mc["map_pose"], mc["nodes"])
+                reps += 1
+            cdt = (time.perf_counter() - t0) / reps
+            line["cpu_baseline"] = dict(value=info["cell_updates"] / cdt, unit="cell updates/s", cores=1,
+                                        kind="port", sample="%d builds of the same 10 scans, map build only, "
+                                        "%.2f ms each" % (reps, cdt * 1e3))
+        print(json.dumps(line), flush=True)
+    ctx.close()
+
+
+# ------------------------------------------------------------------ frontend CSM (configs[1])
+
+def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from csm_hip import api
+
+    n_chunks = max(1, SCANS_PER_STEP // WINDOWS_PER_LAUNCH)
+    n_distinct = max(WINDOWS_PER_LAUNCH, min(DISTINCT_SCANS, n_chunks * WINDOWS_PER_LAUNCH))
+    n_distinct -= n_distinct % WINDOWS_PER_LAUNCH
+    scans_per_step = n_chunks * WINDOWS_PER_LAUNCH
+    wl = make_workload(rank, n_distinct)
+    rx, ry, rt, L = wl["params"]
+    ctx = api.Context(dev_index, tuning_off=args.tuning_off)
+    # a non-default torch stream: csm_set_stream(NULL) would mean "the context's
+    # own stream", and the collectives below must be ordered against the scoring
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload_grid(1, wl["grid"])
+    ctx.build_pyramid(1, [1, L])
+
+    windows, cols, rows_, cands = [], [], [], []
+    for sc in wl["scans"]:
+        wx, wy, wt = sc["win"]
+        windows.append(ctx.make_window(2 * wt + 1, N_BEAMS, wx, wy, L, 1, api.host_min_known(N_BEAMS, 0.0), 0.0))
+        cols.append(torch.from_numpy(sc["col"]).to(dev))
+        rows_.append(torch.from_numpy(sc["row"]).to(dev))
+        nx = -(-(2 * wx + 1) // L) * L
+        ny = -(-(2 * wy + 1) // L) * L
+        cands.append((2 * wt + 1) * nx * ny)
+    rec_bytes = 48
+    results = torch.zeros(scans_per_step * rec_bytes, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * scans_per_step * rec_bytes, dtype=torch.uint8, device=dev)
+    n_batches = n_distinct // WINDOWS_PER_LAUNCH
+    prepared = []
+    for b in range(n_batches):
+        sl = slice(b * WINDOWS_PER_LAUNCH, (b + 1) * WINDOWS_PER_LAUNCH)
+        prepared.append(ctx.prepare_windows([1] * WINDOWS_PER_LAUNCH, windows[sl],
+                                            [c.data_ptr() for c in cols[sl]],
+                                            [r.data_ptr() for r in rows_[sl]]))
+    cands_per_batch = [sum(cands[b * WINDOWS_PER_LAUNCH:(b + 1) * WINDOWS_PER_LAUNCH]) for b in range(n_batches)]
+    cands_per_step = sum(cands_per_batch[k % n_batches] for k in range(n_chunks))
+
+    def step():
+        for k in range(n_chunks):
+            ctx.score_windows_dev(prepared[k % n_batches],
+                                  results.data_ptr() + k * WINDOWS_PER_LAUNCH * rec_bytes)
+        if world > 1:
+            if rehearse:
+                host = results.cpu()
+                out = torch.zeros(world * host.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, host)
+                gathered.copy_(out)
+            else:
+                dist.all_gather_into_tensor(gathered, results)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        # events around the dominant kernel only inside the timed region; the
+        # other kernels are timed in a short extra pass afterwards
+        ctx.lib.csm_enable_kernel_timing(ctx._ctx, 2)
+        ctx.reset_kernel_timing()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        ctx.enable_kernel_timing(False)
+        fine_ms, fine_n = ctx.kernel_time("score_fine")
+        bound_ms, bound_n = ctx.kernel_time("score_bound")      # the packed-fp32 bound pass of the fine level
+        fine_ms += bound_ms
+        blocks_scored, blocks_skipped = ctx.bound_pass_stats()
+        ctx.lib.csm_enable_kernel_timing(ctx._ctx, 1)
+        ctx.reset_kernel_timing()
+        step()
+        fence()
+        ctx.enable_kernel_timing(False)
+    others = {}
+    for name in ("score_coarse", "bin", "finalize"):
+        ms, n = ctx.kernel_time(name)
+        others[name] = ms / max(1, n) * 1e3
+
+    # the same workload through the exact integer kernel alone (no bound pass): reported beside the headline
+    exact_only = None
+    if world == 1 and not args.no_configs and not (args.tuning_off & 256) and blocks_skipped:
+        ctx2 = api.Context(dev_index, tuning_off=args.tuning_off | 256)
+        ctx2.set_stream(stream.cuda_stream)
+        ctx2.upload_grid(1, wl["grid"])
+        ctx2.build_pyramid(1, [1, L])
+        prep2 = [ctx2.prepare_windows([1] * WINDOWS_PER_LAUNCH, windows[b * WINDOWS_PER_LAUNCH:(b + 1) * WINDOWS_PER_LAUNCH],
+                                      [c.data_ptr() for c in cols[b * WINDOWS_PER_LAUNCH:(b + 1) * WINDOWS_PER_LAUNCH]],
+                                      [r.data_ptr() for r in rows_[b * WINDOWS_PER_LAUNCH:(b + 1) * WINDOWS_PER_LAUNCH]])
+                 for b in range(n_batches)]
+        with torch.cuda.stream(stream):
+            for rep in range(3):
+                if rep == 1:
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                for k in range(n_chunks):
+                    ctx2.score_windows_dev(prep2[k % n_batches], results.data_ptr() + k * WINDOWS_PER_LAUNCH * rec_bytes)
+            torch.cuda.synchronize(dev)
+        exact_only = cands_per_step * 2 / (time.perf_counter() - t0)
+        ctx2.close()
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=None if rehearse else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
         # this rank's slice of the gathered buffer must be its own records
         mine = gathered[rank * results.numel():(rank + 1) * results.numel()]
         assert torch.equal(mine, results), "all-gather read the records before they were written"
@@ -770,6 +925,7 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
     rec = np.frombuffer(rec_raw, dtype=np.int32).reshape(scans_per_step, 12)
     n_found = int(rec[:, 0].sum())
     verified = verify_sample(wl, rec_raw, scans_per_step, n_distinct, args.verify) if rank == 0 else 0
+
 
     if rank == 0:
         total = cands_per_step * args.steps * world
@@ -800,7 +956,9 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",   # uint16 cells, exact u32/u64 integer sums; f64 replay of the winner
+            # uint16 cells; packed-fp32 bound pass over every candidate, exact u32 / u64 integer sums for the
+            # candidates within its bound of the maximum; f64 replay of the winner
+            "dtype": "f32+u32",
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: frontend CSM, 1080-beam scan, 400x400@5cm grid, "
@@ -819,13 +977,19 @@ def run_csm_workload(args, rank, world, dev, dev_index, rehearse, stream):
                                "the window's maximum" % (100.0 * blocks_scored / max(1, blocks_scored + blocks_skipped)))
                               if blocks_skipped else "exact integer kernel on every candidate block",
                 "bound_pass_us_per_launch": bound_ms / max(1, bound_n) * 1e3,
+                "exact_integer_kernel_only_poses_per_s": exact_only,
                 "verified": verified,
                 "verified_note": "records of the last timed step compared, after the timed region, with the CPU "
                                  "oracle's literal sweep (best x, y, theta and the f64 score at tolerance 0)",
             },
             "roofline": {
                 "bound": "lds",
-                "kernel": "k_score_pairs2_batch<150, 8> + <156, 6> (fine level of %d windows: the 48-row blocks, then the 36-row blocks; avg_launch_us spans both launches)" % WINDOWS_PER_LAUNCH,
+                "kernel": ("fine level of %d windows: k_score_jointf_batch<156, 8> + <156, 6> (packed-fp32 bound pass: the "
+                           "48-row blocks, then the 36-row blocks) + k_bound_select + k_score_joint_list<156, 8> / <156, 6> "
+                           "(exact kernel on the blocks kept); avg_launch_us spans all of them"
+                           if blocks_skipped else
+                           "fine level of %d windows: the exact kernel's launches (48-row blocks, then the 36-row blocks); "
+                           "avg_launch_us spans them") % WINDOWS_PER_LAUNCH,
                 "achieved": achieved,
                 "peak": LDS_PEAK_GBS,
                 "unit": "GB/s",

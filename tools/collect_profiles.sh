@@ -28,10 +28,9 @@ export CSM_BENCH_SCANS=512 CSM_BENCH_DISTINCT=256
 run_pmc csm FETCH_SIZE --steps 3 --warmup 1 --no-configs --no-cpu-baseline || exit 1
 run_pmc csm WRITE_SIZE --steps 3 --warmup 1 --no-configs --no-cpu-baseline || exit 1
 # configs[4]: the one workload whose maps leave L2 (56 MB pair-row copy, 8 MB grid)
-export CSM_BENCH_SCANS=64 CSM_BENCH_WINDOWS=64 CSM_BENCH_CONFIGS=config5
-run_stats cfg5 --steps 1 --warmup 1 --no-cpu-baseline || exit 1
-run_pmc cfg5 FETCH_SIZE --steps 1 --warmup 1 --no-cpu-baseline || exit 1
-run_pmc cfg5 WRITE_SIZE --steps 1 --warmup 1 --no-cpu-baseline || exit 1
+run_stats cfg5 --workload config5 --steps 5 --warmup 1 || exit 1
+run_pmc cfg5 FETCH_SIZE --workload config5 --steps 2 --warmup 1 || exit 1
+run_pmc cfg5 WRITE_SIZE --workload config5 --steps 2 --warmup 1 || exit 1
 unset CSM_BENCH_SCANS CSM_BENCH_DISTINCT CSM_BENCH_CONFIGS CSM_BENCH_WINDOWS
 # configs[2]: the branch-and-bound batch
 run_stats loop --workload loop --steps 10 --no-cpu-baseline || exit 1
@@ -56,17 +55,18 @@ def counters(name):
 for name, pick, wpl in (("csm", "_batch<", int(os.environ.get("CSM_BENCH_WINDOWS", "256"))), ("cfg5", "k_score_pairs<", 1),
                         ("loop", "_batch<", 256)):
     per = counters(name)
-    dom = [k for k in per if pick in k and "k_score_pairs" in k]
-    if name == "cfg5":      # the 2000x2000 query's kernel: the single-window pair kernel with the widest rows
-        dom = [k for k in dom if "182" in k] or dom
+    if name == "cfg5":      # the coarse-first search: the pair kernel on the phase-major copy + the fine work list
+        dom = [k for k in per if "k_score_pairs<" in k or "k_score_pairs_list<" in k]
+    else:                   # the joint kernels of a batch: fp32 bound pass (if any) + exact kernel
+        dom = [k for k in per if "k_score_joint" in k]
     doc = {"library_version": version, "windows_per_launch": wpl, "per_kernel": per,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over a short "
                      "bench.py run; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per the gfx950 note "
                      "in MI355X_MICROARCH.md (HBM section)"}
     if dom:
-        # the fine level of a batch is one launch per row-block shape (R = 8 blocks, then the R = 6 tail
-        # block): the level's bytes are the sum over those launches
-        dom = dom[:1] if name == "cfg5" else sorted(dom)
+        # the level is several launches (bound pass and exact kernel, each once per row-block shape;
+        # coarse pass + fine work list for the coarse-first search): its bytes are their sum
+        dom = sorted(dom)
         f = sum(per[k].get("FETCH_SIZE", {}).get("mean_KB", 0.0) for k in dom)
         w = sum(per[k].get("WRITE_SIZE", {}).get("mean_KB", 0.0) for k in dom)
         doc.update(kernel=" + ".join(dom), FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, hbm_bytes_per_launch=(2 * f + w) * 1024)
