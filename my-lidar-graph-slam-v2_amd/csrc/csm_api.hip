@@ -702,8 +702,9 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
     return CSM_OK;
 }
 
-/* Template dispatch: stride-1 kernels for LSTRIDE in {96,128,160,192} x R in
- * {4..8}; strided kernels for LSTRIDE in {128,192} x R in {1,2,4}. */
+/* Template dispatch of the strided kernels (coarser levels): LSTRIDE in {128,192} x R in {1,2,4},
+ * stride a power of two (MODE 1) or any (MODE 2). The stride-1 level is always a pair kernel
+ * (PAIR_DISPATCH); round 1's stride-1 body survives only as the arg-max pass (k_argmax). */
 #define SCORE_CASE(LS, RR, ST, CALL)                                                   \
     if (pp.lstride == LS && pp.R == RR && mode == ST) {                                \
         if (pp.weighted || ST != 0) {                                                  \
@@ -717,21 +718,11 @@ int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
 /* tuning builds (tools/build_variant.sh): only the instantiations bench.py's configs[1] uses */
 #define SCORE_DISPATCH(CALL)                                                           \
     do {                                                                               \
-        SCORE_CASE(160, 7, 0, CALL) SCORE_CASE(192, 1, 1, CALL)                        \
+        SCORE_CASE(192, 1, 1, CALL)                                                    \
     } while (0)
 #else
 #define SCORE_DISPATCH(CALL)                                                           \
     do {                                                                               \
-        SCORE_CASE(96, 4, 0, CALL) SCORE_CASE(96, 5, 0, CALL)                          \
-        SCORE_CASE(96, 6, 0, CALL) SCORE_CASE(96, 7, 0, CALL)                          \
-        SCORE_CASE(96, 8, 0, CALL) SCORE_CASE(128, 4, 0, CALL)                         \
-        SCORE_CASE(128, 5, 0, CALL) SCORE_CASE(128, 6, 0, CALL)                        \
-        SCORE_CASE(128, 7, 0, CALL) SCORE_CASE(128, 8, 0, CALL)                        \
-        SCORE_CASE(160, 4, 0, CALL) SCORE_CASE(160, 5, 0, CALL)                        \
-        SCORE_CASE(160, 6, 0, CALL) SCORE_CASE(160, 7, 0, CALL)                        \
-        SCORE_CASE(160, 8, 0, CALL) SCORE_CASE(192, 4, 0, CALL)                        \
-        SCORE_CASE(192, 5, 0, CALL) SCORE_CASE(192, 6, 0, CALL)                        \
-        SCORE_CASE(192, 7, 0, CALL) SCORE_CASE(192, 8, 0, CALL)                        \
         SCORE_CASE(128, 1, 1, CALL) SCORE_CASE(128, 2, 1, CALL)                        \
         SCORE_CASE(128, 4, 1, CALL) SCORE_CASE(192, 1, 1, CALL)                        \
         SCORE_CASE(192, 2, 1, CALL) SCORE_CASE(192, 4, 1, CALL)                        \
@@ -984,14 +975,7 @@ int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n
         pp.lstride = 128;        /* k_argmax<128, 6 | 8> exist */
     const dim3 grid(pp.ncb(), n_theta, 1);
     bool launched = false;
-#ifdef CSM_FAST_BUILD
-    ARGMAX_CASE(128, 8) ARGMAX_CASE(128, 6) ARGMAX_CASE(160, 7)
-#else
-    ARGMAX_CASE(96, 4) ARGMAX_CASE(96, 5) ARGMAX_CASE(96, 6) ARGMAX_CASE(96, 7) ARGMAX_CASE(96, 8)
-    ARGMAX_CASE(128, 4) ARGMAX_CASE(128, 5) ARGMAX_CASE(128, 6) ARGMAX_CASE(128, 7) ARGMAX_CASE(128, 8)
-    ARGMAX_CASE(160, 4) ARGMAX_CASE(160, 5) ARGMAX_CASE(160, 6) ARGMAX_CASE(160, 7) ARGMAX_CASE(160, 8)
-    ARGMAX_CASE(192, 4) ARGMAX_CASE(192, 5) ARGMAX_CASE(192, 6) ARGMAX_CASE(192, 7) ARGMAX_CASE(192, 8)
-#endif
+    ARGMAX_CASE(128, 8) ARGMAX_CASE(128, 6)
     if (!launched)
         return fail(ctx, CSM_EINVAL, "internal: no arg-max kernel for lstride %d R %d", pp.lstride, pp.R);
     HIP_TRY(ctx, hipGetLastError());
@@ -2968,8 +2952,11 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     /* ---- launch geometry shared by the group ---- */
     std::vector<PassPlan> lp(H + 1);
     for (int h = 0; h <= H; ++h) {
-        if (h == 0 && plan_pass_pairs(ctx->tune, nx, ny, &lp[0], true))
+        if (h == 0) {
+            if (!plan_pass_pairs(ctx->tune, nx, ny, &lp[0], true))
+                return fail(ctx, CSM_EINVAL, "no launch geometry for the fine level");
             continue;
+        }
         if (!plan_pass(ctx->tune, nx / spec.stride[h], ny / spec.stride[h], spec.stride[h], &lp[h]))
             return fail(ctx, CSM_EINVAL, "no launch geometry for level %d (stride %d)", h,
                         spec.stride[h]);
