@@ -40,8 +40,9 @@ constexpr int kBinjBlock = 512;      /* threads per workgroup of the joint binni
 
 /* One workgroup (kBinjBlock threads) per PAIR of theta slices (2p, 2p + 1; the last pair of
  * an odd number of slices holds one). Entry words:
- *   sorted_pb: m_o1 << 28 | m_e1 << 24 | m_o0 << 20 | m_e0 << 16 | slot
- *              slot = pair_row * lstride + col inside the tile's bounding box (< 16384)
+ *   sorted_pb: m_o1 << 28 | m_e1 << 24 | m_o0 << 20 | m_e0 << 16 | byte offset of the slot
+ *              = (pair_row * lstride + col) * 8 inside the tile's bounding box (< 2^16: at most 31
+ *              pair rows of at most 262 slots)
  *   sorted_rc: the same counts | row << 7 | col (row even, rows / cols inside the bounding
  *              box; the strided kernels of the coarser levels pick the counts of their slice)
  * Lists, records and record counts are indexed by the pair: sorted_pb + p * 2 n_points,
@@ -324,7 +325,7 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
             b2 -= m2;
             b3 -= m3;
             const uint32_t mults = (m0 << 16) | (m1 << 20) | (m2 << 24) | (m3 << 28);
-            out[pos] = mults | ((rb >> 1) * lstride + cb);
+            out[pos] = mults | (((rb >> 1) * lstride + cb) << 3);       /* byte offset of the slot: < 2^16 */
             if (out_rc)
                 out_rc[pos] = mults | (rb << 7) | cb;
         }
@@ -424,7 +425,7 @@ __device__ __forceinline__ void joint_gather(uint32_t lane_addr, const uint32_t*
         }
     };
     auto issue = [&](uint32_t w, unsigned long long (&q)[NQ]) {
-        const uint32_t addr = lane_addr + ((w & 0x3fffu) << 3);
+        const uint32_t addr = lane_addr + (w & 0xffffu);
         lds_read_b64<0 * kRowBytes>(addr, q[0]);
         lds_read_b64<1 * kRowBytes>(addr, q[1]);
         lds_read_b64<2 * kRowBytes>(addr, q[2]);
@@ -732,17 +733,24 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
     constexpr int kRowBytes = LS * 8;
     constexpr int NQ = R / 2 + 1;
     constexpr int NP = NQ + 2;                      /* reads per entry */
-    auto issue = [&](uint32_t w, uint32_t faddr, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
-        const uint32_t addr = lane_addr + ((w & 0x3fffu) << 3);
+    /* K: the entry's position in its group of four (its float-table row is an immediate offset from
+     * the group's row: one address register per group) */
+    auto issue = [&](uint32_t w, uint32_t faddr, auto kk, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
+        constexpr int K = decltype(kk)::value;
+        const uint32_t addr = lane_addr + (w & 0xffffu);
         lds_read_b64<0 * kRowBytes>(addr, q[0]);
         lds_read_b64<1 * kRowBytes>(addr, q[1]);
         lds_read_b64<2 * kRowBytes>(addr, q[2]);
         lds_read_b64<3 * kRowBytes>(addr, q[3]);
         if (R >= 8)
             lds_read_b64<4 * kRowBytes>(addr, q[4]);
-        lds_read_b64<0>(faddr, f[0]);
-        lds_read_b64<8>(faddr, f[1]);
+        lds_read_b64<16 * K>(faddr, f[0]);
+        lds_read_b64<16 * K + 8>(faddr, f[1]);
     };
+    using k0 = std::integral_constant<int, 0>;
+    using k1 = std::integral_constant<int, 1>;
+    using k2 = std::integral_constant<int, 2>;
+    using k3 = std::integral_constant<int, 3>;
     /* waits until all but the `LATER` youngest LDS reads have landed; ties every register the
      * mads are about to read */
     auto wait = [&](auto later, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
@@ -765,14 +773,14 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
             const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
             const uint32_t fbase = ftab_addr + (uint32_t)j * 16u;
             unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ], fa[2], fb[2], fc[2], fd[2];
-            issue(o0, fbase, qa, fa);
-            issue(o1, fbase + 16u, qb, fb);
+            issue(o0, fbase, k0(), qa, fa);
+            issue(o1, fbase, k1(), qb, fb);
             wait(later_t(), qa, fa);
             joint_fmads<R>(o0, qa, fa[0], fa[1], ea, oa, eb, ob);
-            issue(o2, fbase + 32u, qc, fc);
+            issue(o2, fbase, k2(), qc, fc);
             wait(later_t(), qb, fb);
             joint_fmads<R>(o1, qb, fb[0], fb[1], ea, oa, eb, ob);
-            issue(o3, fbase + 48u, qd, fd);
+            issue(o3, fbase, k3(), qd, fd);
             wait(later_t(), qc, fc);
             joint_fmads<R>(o2, qc, fc[0], fc[1], ea, oa, eb, ob);
             wait(now_t(), qd, fd);
@@ -781,7 +789,7 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
         for (; j < stop; ++j) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
             unsigned long long qa[NQ], fa[2];
-            issue(o, ftab_addr + (uint32_t)j * 16u, qa, fa);
+            issue(o, ftab_addr + (uint32_t)j * 16u, k0(), qa, fa);
             wait(now_t(), qa, fa);
             joint_fmads<R>(o, qa, fa[0], fa[1], ea, oa, eb, ob);
         }
@@ -897,8 +905,13 @@ __device__ __forceinline__ void score_body_jointf(const ScoreJob& job, int cbx, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t lane_addr = lds_address(sm_cells) + (uint32_t)(tb + 8 * a);
+#ifndef CSM_ABL_NOGATHER       /* timing builds only (tools/build_variant.sh): what the tile loop costs without its gather */
         if (wave_live)
             joint_gather_f<LS, R>(lane_addr, lds_address(ftab), lpb, lane, cnt, ea, oa, eb, ob);
+#else
+        if (wave_live && cnt < 0)
+            joint_gather_f<LS, R>(lane_addr, lds_address(ftab), lpb, lane, cnt, ea, oa, eb, ob);
+#endif
     }
 
     /* this lane's candidates: column bx * cbx + dxi, rows row0 + g * R + r */
