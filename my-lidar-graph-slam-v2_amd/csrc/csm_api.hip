@@ -2970,13 +2970,15 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     }
     /* Joint entry lists of slice pairs (k_binj + k_score_joint_batch, csm_joint_kernels.hip): the
      * two-slice plan with merged (weighted) entries, when the joint hash table of every query
-     * leaves room for two binning workgroups (8 waves each) per CU. Otherwise round 2's per-slice lists. */
+     * fits a CU's LDS. Otherwise round 2's per-slice lists. */
     size_t binj_lds = 0;
     for (int k = 0; k < nq; ++k)
         binj_lds = std::max(binj_lds, csm::binj_lds_bytes(pp[k].tiles_x * pp[k].tiles_y, pp[k].n,
                                                           bin_hash_size(2 * pp[k].n)));
     const bool joint = ctx->tune.joint && lp[0].pairs && lp[0].lists == 2 && lp[0].weighted &&
-                       binj_lds <= 78 * 1024;      /* two binning workgroups per CU */
+                       binj_lds <= 150 * 1024;     /* up to ~1,365 beams two binning workgroups share a CU; above
+                                                      that one (the fine level's gain outweighs the slower binning),
+                                                      up to ~5,400 beams per scan */
     lp[0].joint = joint;
     /* The packed-fp32 bound pass in front of the exact kernel: only where the arg-max is over ALL
      * candidates of the window -- the correlative sweep with a known-rate threshold that the coarse

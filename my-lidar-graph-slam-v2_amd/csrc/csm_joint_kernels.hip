@@ -430,7 +430,7 @@ __device__ __forceinline__ void joint_gather(uint32_t lane_addr, const uint32_t*
         lds_read_b64<1 * kRowBytes>(addr, q[1]);
         lds_read_b64<2 * kRowBytes>(addr, q[2]);
         lds_read_b64<3 * kRowBytes>(addr, q[3]);
-        if (R >= 8)
+        if constexpr (R >= 8)
             lds_read_b64<4 * kRowBytes>(addr, q[4]);
     };
     auto mads = [&](uint32_t w, const unsigned long long (&q)[NQ]) {
@@ -742,7 +742,7 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
         lds_read_b64<1 * kRowBytes>(addr, q[1]);
         lds_read_b64<2 * kRowBytes>(addr, q[2]);
         lds_read_b64<3 * kRowBytes>(addr, q[3]);
-        if (R >= 8)
+        if constexpr (R >= 8)
             lds_read_b64<4 * kRowBytes>(addr, q[4]);
         lds_read_b64<16 * K>(faddr, f[0]);
         lds_read_b64<16 * K + 8>(faddr, f[1]);
