@@ -1,5 +1,10 @@
 /* csm_cost_api.hip -- host side of the batched cost / covariance / linear-solver
- * entry points (included by csm_api.hip). */
+ * entry points, with their kernels (csm_cost_kernels.hip). A translation unit of
+ * libcsm_hip.so of its own. */
+#include "csm_internal.hpp"
+
+#include "csm_cost_kernels.hip"
+
 
 namespace {
 

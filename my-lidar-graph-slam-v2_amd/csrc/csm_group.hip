@@ -1,5 +1,5 @@
 /* csm_group.hip -- several GPUs behind one detector object, inside ONE process
- * (included by csm_api.hip: it needs the context's internals).
+ * (a translation unit of libcsm_hip.so of its own, host code only).
  *
  * The reference's precedent is LoopDetectorFPGAParallel
  * (src/mapping/loop_detector_fpga_parallel.cpp:42-56): Detect() splits the query
@@ -19,6 +19,8 @@
  * The summaries themselves are written by the member threads straight into the
  * caller's array: one address space, no gather needed for them.
  */
+#include "csm_internal.hpp"
+
 #include <dlfcn.h>
 
 #include <set>

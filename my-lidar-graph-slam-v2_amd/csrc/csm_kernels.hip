@@ -37,12 +37,6 @@
 
 namespace csm {
 
-/* PositionToIndex on device, IEEE double, no contraction: bit-identical to
- * src/grid_map_new/grid_map_geometry.cpp:113-122 */
-__device__ __forceinline__ int cell_index(double pos, double off, double res)
-{
-    return (int)floor((pos - off) / res);
-}
 
 #ifdef CSM_BIN_TIMING
 /* tuning builds only: cycles per phase of k_bin, one row of 8 counters per workgroup
@@ -1876,15 +1870,6 @@ __global__ __launch_bounds__(256) void k_scatter_records(const csm_result* src, 
     d[2] = s[2];
 }
 
-/* Bound on |q_host - q_device| for q = (sensor + r*trig - off) / res, in cells.
- * `trig_err`: absolute error of the device's cosine / sine against the host's
- * cos(arg) / sin(arg) (see proj_body); then one rounding per arithmetic step on
- * either side; the caller multiplies by a safety factor. */
-__device__ __forceinline__ double proj_err_bound(double r, double hit, double off, double res,
-                                                 double q, double trig_err)
-{
-    return (fabs(r) * trig_err + (fabs(hit) + fabs(off)) * 4e-16) / res + fabs(q) * 4e-16;
-}
 
 /* grid = (beam blocks, theta groups, jobs): a thread owns one beam and walks the
  * theta slices blockIdx.y, blockIdx.y + gridDim.y, ...

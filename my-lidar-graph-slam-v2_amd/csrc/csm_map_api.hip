@@ -1,7 +1,12 @@
 /* csm_map_api.hip -- host side of the map updates: csm_construct_map_from_scans
- * and csm_update_map_with_scan (include/csm_hip.h). Not a translation unit of
- * its own: csm_api.hip includes it inside its extern "C" block, after the
- * context, buffer and level helpers it uses. */
+ * and csm_update_map_with_scan (include/csm_hip.h), with their kernels
+ * (csm_map_kernels.hip). A translation unit of libcsm_hip.so of its own. */
+#include "csm_internal.hpp"
+
+#include "csm_map_kernels.hip"
+
+extern "C" {
+
 /* ---- map building ---- */
 
 namespace {
@@ -508,3 +513,5 @@ int csm_update_map_with_scan(csm_ctx* ctx, uint64_t map_id, csm_map_shape* shape
 {
     return map_build(ctx, map_id, shape, global_map_pose, node, node ? 1 : 0, prm, info, true);
 }
+
+} /* extern "C" */

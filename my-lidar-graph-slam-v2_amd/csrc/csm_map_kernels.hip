@@ -1,10 +1,12 @@
 /* csm_map_kernels.hip -- device side of the map updates
  * (GridMapBuilder::ConstructMapFromScans / UpdateGridMap,
  * src/my_lidar_graph_slam/mapping/grid_map_builder.cpp:389-494, 561-695).
- * Included by csm_api.hip after csm_kernels.hip (uses its cell_index and
- * proj_err_bound). gfx950 only. */
+ * Included by csm_map_api.hip (its own translation unit); cell_index and
+ * proj_err_bound come from csm_score_common.hpp. gfx950 only. */
 #ifndef CSM_MAP_KERNELS_HIP
 #define CSM_MAP_KERNELS_HIP
+
+#include "csm_score_common.hpp"
 
 namespace csm {
 

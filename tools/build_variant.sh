@@ -6,10 +6,12 @@ set -e
 NAME="$1"; shift
 cd "$(dirname "$0")/../my-lidar-graph-slam-v2_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -DCSM_FAST_BUILD -DCSM_TUNING"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c -o "v_$NAME.api.o" csm_api.hip &
-/opt/rocm/bin/hipcc $FLAGS "$@" -c -o "v_$NAME.joint.o" csm_joint_kernels.hip &
-/opt/rocm/bin/hipcc $FLAGS "$@" -c -o "v_$NAME.phase.o" csm_phase_kernels.hip &
+OBJS=""
+for u in csm_api csm_joint_kernels csm_phase_kernels csm_map_api csm_cost_api csm_group; do
+    /opt/rocm/bin/hipcc $FLAGS "$@" -c -o "v_$NAME.$u.o" $u.hip &
+    OBJS="$OBJS v_$NAME.$u.o"
+done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "libcsm_hip_$NAME.so" "v_$NAME.api.o" "v_$NAME.joint.o" "v_$NAME.phase.o"
-rm -f "v_$NAME.api.o" "v_$NAME.joint.o" "v_$NAME.phase.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "libcsm_hip_$NAME.so" $OBJS
+rm -f $OBJS
 echo "built libcsm_hip_$NAME.so"
