@@ -2731,9 +2731,13 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
      * level passes whenever a fine candidate scores at all (min_known <= 1; a touched edge band
      * switches the skipping off per query on the device). Branch and bound tests every leaf's own
      * known count: exact kernel only. */
-    bool bound_pass = joint && ctx->tune.bound_pass && !spec.bnb && nq < (1 << 14) && lp[0].ncb() <= 256 &&
+    bool bound_pass = joint && ctx->tune.bound_pass && nq < (1 << 14) && lp[0].ncb() <= 256 &&
                       (n_theta_max + 1) / 2 <= 1024;       /* the work list's item format */
-    for (int k = 0; k < nq && bound_pass; ++k)
+    /* Branch and bound tests every leaf's own known count, which the bound pass does not see: there
+     * the exact pass runs in two rounds (k_bound_select). The correlative sweep with a known-rate
+     * threshold above one beam tests the COARSE node's count: exact kernel on every block. */
+    const bool two_rounds = spec.bnb;
+    for (int k = 0; k < nq && bound_pass && !spec.bnb; ++k)
         bound_pass = (resident ? resident->windows[idx[k]].min_known
                                : csm_host_min_known(pp[k].n, spec.known_thr)) <= 1;
     for (int k = 0; k < nq; ++k) {
@@ -3010,6 +3014,14 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
              * least max_fp32 * (1 - 3 (n + 3) 2^-24); the kernel compares with 4 (n + 3) 2^-24. */
             F.approx_slack = 4.0f * (float)(p.n + 3) * 5.9604645e-08f;
             F.bound_stats = reinterpret_cast<uint32_t*>(ctx->bound_stats.p);
+            /* found <=> sum of probabilities / n > threshold, and that sum is (0.998 / 65534 / 499) * key
+             * up to the f64 rounding of the beam-order summation (1e-12 relative): a candidate below
+             * this key cannot be reported */
+            const double thr = resident ? resident->windows[idx[k]].score_threshold : spec.score_thr;
+            F.key_floor = thr > 0.0 ? (float)(thr * p.n * (65534.0 * 499.0 / 0.998) * (1.0 - 1e-9)) *
+                                          (1.0f - F.approx_slack)
+                                    : 0.0f;
+            F.round1_record = resident ? (const void*)(resident->out_dev + idx[k]) : (const void*)(d_out + k);
             if (resident && resident->dump_f)
                 F.dump_f = resident->dump_f[idx[k]];
         }
@@ -3156,6 +3168,17 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, fp, n_theta_max, 1)))
             return rc;
     }
+    auto finalize = [&]() -> int {
+        const size_t lds = (size_t)n_points_max * 8;
+        int rc2 = set_lds(ctx, k_finalize_batch, lds);
+        if (rc2)
+            return rc2;
+        ScopedTimer tm(ctx, "finalize");
+        hipLaunchKernelGGL(k_finalize_batch, dim3(nq), dim3(kBlock), lds, ctx->stream,
+                           reinterpret_cast<const FinalJob*>(d_fj));
+        HIP_TRY(ctx, hipGetLastError());
+        return CSM_OK;
+    };
     if (bound_pass) {
         size_t blocks_total = 0;
         for (int k = 0; k < nq; ++k)
@@ -3168,29 +3191,30 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         list.items[1] = items1;
         list.counts = counts;
         list.blocks = (int)std::min<size_t>(blocks_total, 2048);
-        ScopedTimer tm(ctx, "score_fine");
-        HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, ctx->stream));
         const int split_cb = tail_split(ctx, lp[0]) ? lp[0].ncbx * (lp[0].ncby - 1) : ncb;
-        const int e = csm::launch_bound_select(ctx->stream, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, ncb, split_cb,
-                                               items0, items1, counts, (uint32_t)blocks_total);
-        if (e != 0)
-            return fail(ctx, CSM_EIO, "k_bound_select launch failed: %s", hipGetErrorString((hipError_t)e));
-        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0], n_theta_max, 1, 0,
-                                     &list)))
-            return rc;
+        for (int round = 1; round <= (two_rounds ? 2 : 1); ++round) {
+            {
+                ScopedTimer tm(ctx, "score_fine");
+                HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, ctx->stream));
+                const int e = csm::launch_bound_select(ctx->stream, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, ncb,
+                                                       split_cb, items0, items1, counts, (uint32_t)blocks_total, round);
+                if (e != 0)
+                    return fail(ctx, CSM_EIO, "k_bound_select launch failed: %s", hipGetErrorString((hipError_t)e));
+                if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0], n_theta_max, 1,
+                                             0, &list)))
+                    return rc;
+            }
+            if ((rc = finalize()))
+                return rc;
+        }
     } else {
-        ScopedTimer tm(ctx, "score_fine");
-        if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0],
-                                     n_theta_max, 1)))
+        {
+            ScopedTimer tm(ctx, "score_fine");
+            if ((rc = launch_score_batch(ctx, reinterpret_cast<const ScoreJob*>(d_sj[0]), nq, lp[0], n_theta_max, 1)))
+                return rc;
+        }
+        if ((rc = finalize()))
             return rc;
-    }
-    {
-        const size_t lds = (size_t)n_points_max * 8;
-        if ((rc = set_lds(ctx, k_finalize_batch, lds))) return rc;
-        ScopedTimer tm(ctx, "finalize");
-        hipLaunchKernelGGL(k_finalize_batch, dim3(nq), dim3(kBlock), lds, ctx->stream,
-                           reinterpret_cast<const FinalJob*>(d_fj));
-        HIP_TRY(ctx, hipGetLastError());
     }
     if (resident) {
         /* asynchronous: the records stay on the device. The pinned block the job tables

@@ -172,6 +172,14 @@ struct ScoreJob {
     float approx_slack;
     int32_t pad1;
     uint32_t* bound_stats;     /* optional [2]: blocks the exact kernel scored / skipped after the bound pass */
+    /* fp32 key below which no candidate can be reported as found (score threshold as a key, margin
+     * included; 0: none): blocks below it are never scored */
+    float key_floor;
+    int32_t pad2;
+    /* two-round exact pass (branch and bound: the winner must pass its own known-count test, so the
+     * window's greatest fp32 key may belong to a leaf that does not count): the query's record after
+     * round 1 (csm_result*), whose key is the best ELIGIBLE exact key so far */
+    const void* round1_record;
 };
 
 /* Reduce block results, replay the winner in f64, write the result record. */

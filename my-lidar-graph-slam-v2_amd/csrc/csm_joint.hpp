@@ -44,9 +44,11 @@ int launch_joint_batch(const JointLaunch& launch);
 
 /* After the bound pass (approx_best of every job written): clears every job's BlockBest records and
  * lists the candidate blocks the exact kernel has to score: item = job << 18 | pair << 8 | block;
- * blocks >= split_cb go to items1 (the row block of the R = 6 launch). counts[2] must be zero. */
+ * blocks >= split_cb go to items1 (the row block of the R = 6 launch). counts[2] must be zero.
+ * round 1: as described; round 2 (two-round exact pass, ScoreJob.round1_record): the blocks not listed
+ * in round 1 that can still reach the best eligible key of round 1. */
 int launch_bound_select(hipStream_t stream, const ScoreJob* jobs_dev, int n_jobs, int ncb, int split_cb,
-                        uint32_t* items0, uint32_t* items1, uint32_t* counts, uint32_t cap);
+                        uint32_t* items0, uint32_t* items1, uint32_t* counts, uint32_t cap, int round);
 
 /* xgf = the level's fp32 key copy in the layout of its pair-row copy (k_expand_pairs_f) */
 int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, int cols, int pitch, float* xgf,

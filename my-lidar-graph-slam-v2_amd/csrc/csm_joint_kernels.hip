@@ -984,26 +984,39 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_joint_batch(const ScoreJob*
  * reads (list 0: row blocks of the R = 8 launch, list 1: the window's last row block when that is
  * an R = 6 launch). All blocks are kept when a beam can reach the negative edge band (eligibility
  * against the coarser level then decides, which the bound pass ignores) or when every candidate's
- * sums are wanted (dump_s / dump_k). item = job << 18 | pair << 8 | block. */
+ * sums are wanted (dump_s / dump_k). item = job << 18 | pair << 8 | block.
+ *
+ * Blocks whose maximum lies below the score threshold's key (key_floor) can hold no candidate that
+ * is reported as found and are never scored.
+ *
+ * round 2 (branch and bound). There the winner must also pass its own known-count test, which the
+ * bound pass does not see: M may belong to a leaf that does not count, and the best ELIGIBLE leaf
+ * may lie below M's margin. After round 1 (blocks near M, scored exactly, reduced by k_finalize)
+ * the query's record holds the best eligible exact key B so far; a leaf can only reach or beat B
+ * with an fp32 key >= B (1 - slack), so round 2 lists the blocks not scored yet whose maximum
+ * reaches that (and the floor). After it no unscored block can hold the winner or a tie with it:
+ * two rounds always suffice. Blocks listed in round 1 are marked by a negative approx_best. */
 __global__ __launch_bounds__(256) void k_bound_select(const ScoreJob* jobs, int ncb, int split_cb,
                                                      uint32_t* items0, uint32_t* items1, uint32_t* counts,
-                                                     uint32_t cap)
+                                                     uint32_t cap, int round)
 {
     __shared__ float wmax[4];
     const ScoreJob& job = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     const int n_theta = job.n_theta;
     const int total = n_theta * ncb;
-    const float* ab = job.approx_best;
+    float* ab = job.approx_best;
     float m = 0.f;
-    for (int i = tid; i < total; i += 256) {
-        m = fmaxf(m, ab[i]);
-        BlockBest none;
-        none.key = 0;
-        none.rank = ~0ull;
-        none.count = 0;
-        none.pad = 0;
-        job.block_best[i] = none;
+    if (round == 1) {
+        for (int i = tid; i < total; i += 256) {
+            m = fmaxf(m, ab[i]);
+            BlockBest none;
+            none.key = 0;
+            none.rank = ~0ull;
+            none.count = 0;
+            none.pad = 0;
+            job.block_best[i] = none;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
@@ -1012,15 +1025,27 @@ __global__ __launch_bounds__(256) void k_bound_select(const ScoreJob* jobs, int 
         wmax[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    const float thr = m * (1.0f - job.approx_slack);
-    const bool all = job.dump_s || job.dump_k || (job.elig_only_if_band && (*job.flags & kFlagBandTouch));
+    float thr = fmaxf(m * (1.0f - job.approx_slack), job.key_floor);
+    const bool all_blocks = job.dump_s || job.dump_k || (job.elig_only_if_band && (*job.flags & kFlagBandTouch));
+    const bool all = all_blocks && round == 1;
+    if (round == 2) {
+        if (all_blocks)
+            return;                             /* everything was scored in round 1 */
+        const unsigned long long best = reinterpret_cast<const csm_result*>(job.round1_record)->key;
+        thr = fmaxf((float)best * (1.0f - job.approx_slack), job.key_floor);
+    }
     const int n_pairs = (n_theta + 1) / 2;
     uint32_t kept = 0, dropped = 0;
     for (int i = tid; i < n_pairs * ncb; i += 256) {
         const int pr = i / ncb, cb = i - pr * ncb;
         const int t0 = 2 * pr;
-        const float mine = fmaxf(ab[(size_t)t0 * ncb + cb], t0 + 1 < n_theta ? ab[(size_t)(t0 + 1) * ncb + cb] : 0.f);
+        const float a0 = ab[(size_t)t0 * ncb + cb], a1 = t0 + 1 < n_theta ? ab[(size_t)(t0 + 1) * ncb + cb] : 0.f;
+        if (a0 < 0.f)
+            continue;                           /* scored in round 1 */
+        const float mine = fmaxf(a0, a1);
         if (all || mine >= thr) {
+            if (round == 1)
+                ab[(size_t)t0 * ncb + cb] = -1.0f;
             const int which = cb >= split_cb ? 1 : 0;
             const uint32_t pos = atomicAdd(counts + which, 1u);
             if (pos < cap)
@@ -1050,8 +1075,10 @@ __global__ __launch_bounds__(256) void k_bound_select(const ScoreJob* jobs, int 
         if (tid == 0) {
             if (tot[0])
                 atomicAdd(job.bound_stats, tot[0]);
-            if (tot[1])
+            if (round == 1 && tot[1])
                 atomicAdd(job.bound_stats + 1, tot[1]);
+            if (round == 2 && tot[0])
+                atomicSub(job.bound_stats + 1, tot[0]);     /* counted as skipped after round 1 */
         }
     }
 }
@@ -1155,10 +1182,10 @@ int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, i
 }
 
 int launch_bound_select(hipStream_t stream, const ScoreJob* jobs_dev, int n_jobs, int ncb, int split_cb,
-                        uint32_t* items0, uint32_t* items1, uint32_t* counts, uint32_t cap)
+                        uint32_t* items0, uint32_t* items1, uint32_t* counts, uint32_t cap, int round)
 {
     hipLaunchKernelGGL(k_bound_select, dim3(n_jobs), dim3(256), 0, stream, jobs_dev, ncb, split_cb, items0, items1,
-                       counts, cap);
+                       counts, cap, round);
     return (int)hipGetLastError();
 }
 
