@@ -72,3 +72,48 @@ def test_bnb_relative_sensor_pose_and_shared_map(gpu_ctx, oracle):
         assert o["raw"]["score"] == want["scoreMax"]
         assert o["estimated_pose"] == want["estimatedPose"]
     gpu_ctx.release_grid(7)
+
+
+def test_bnb_winner_far_below_an_ineligible_maximum(gpu_ctx, oracle):
+    """The two-round exact pass behind the fp32 bound pass (k_bound_select): the window's greatest
+    key belongs to leaves that fail their own known-count test (a third of the beams on saturated
+    cells, the rest on unknown ones), the true winner -- every beam on a dim wall -- scores an order
+    of magnitude lower. Round 1 scores the blocks near the maximum and finds nothing eligible (or
+    something small); round 2 must pick up the blocks that can still hold the winner."""
+    qs, cases = [], []
+    for i, seed in enumerate([81, 82, 83, 84]):
+        case = synth.csm_case(seed, n_beams=1080, fov=1.5 * math.pi, init_error=(0.3, -0.2, 0.04))
+        g0 = case["grid"]
+        g = np.where(g0 > 30000, 1500, 0).astype(np.uint16)          # only the walls are known, and dim
+        sx, sy, st = api.host_search_step(case["geom"][0], case["ranges"])
+        col, row = api.host_project(case["geom"], case["truth"], st, 0, case["angles"], case["ranges"])
+        n = len(case["angles"])
+        sel = np.arange(n) < int(0.35 * n)                            # a third of the beams ...
+        rr = np.clip(row[0][sel] + 13 + i, 0, g.shape[0] - 1)         # ... land on bright cells at a shifted pose
+        cc = np.clip(col[0][sel] + 20 - i, 0, g.shape[1] - 1)
+        g[rr, cc] = 65535
+        case["grid"] = g
+        cases.append(case)
+        qs.append(dict(map_id=1300 + i, geom=case["geom"], angles=case["angles"], ranges=case["ranges"],
+                       rel_pose=case["rel_pose"], init_pose=case["init_pose"]))
+        gpu_ctx.upload_grid(1300 + i, g)
+    rx, ry, rt, H = 2.5, 2.5, 0.5, 2
+    gpu_ctx.bound_pass_stats()
+    outs = gpu_ctx.bnb_match_batch(qs, rx, ry, rt, H, 0.005, 0.6)
+    scored, skipped = gpu_ctx.bound_pass_stats()
+    assert scored > 0          # (round 2 may well end up scoring every block here: nothing eligible near the maximum)
+    n_found = 0
+    for q, c, o in zip(qs, cases, outs):
+        want = oracle.bnb(c, rx, ry, rt, H, 0.005, 0.6)
+        raw = o["raw"]
+        assert o["pose_found"] == want["found"], (raw, want)
+        if raw["flags"] == 0:
+            assert (raw["best_x"], raw["best_y"], raw["best_theta"]) == (want["bestX"], want["bestY"], want["bestT"])
+            assert raw["score"] == want["scoreMax"]
+        assert o["estimated_pose"] == want["estimatedPose"]
+        n_found += want["found"]
+        # the winner really lies far below the window's greatest key: the bright cluster outscores it
+        assert want["scoreMax"] < 0.1
+    assert n_found >= 1
+    for q in qs:
+        gpu_ctx.release_grid(q["map_id"])
