@@ -2733,13 +2733,15 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
      * known count: exact kernel only. */
     bool bound_pass = joint && ctx->tune.bound_pass && nq < (1 << 14) && lp[0].ncb() <= 256 &&
                       (n_theta_max + 1) / 2 <= 1024;       /* the work list's item format */
-    /* Branch and bound tests every leaf's own known count, which the bound pass does not see: there
-     * the exact pass runs in two rounds (k_bound_select). The correlative sweep with a known-rate
-     * threshold above one beam tests the COARSE node's count: exact kernel on every block. */
-    const bool two_rounds = spec.bnb;
-    for (int k = 0; k < nq && bound_pass && !spec.bnb; ++k)
-        bound_pass = (resident ? resident->windows[idx[k]].min_known
-                               : csm_host_min_known(pp[k].n, spec.known_thr)) <= 1;
+    /* Where the winner must pass a known-count test the bound pass does not see -- branch and bound:
+     * every leaf's own count; the correlative sweep with a known-rate threshold above one beam: the
+     * coarse node's count (the reference's loop detectors run with 0.6) -- the window's greatest
+     * fp32 key may belong to a candidate that does not count, and the exact pass runs in two rounds
+     * (k_bound_select). */
+    bool two_rounds = spec.bnb;
+    for (int k = 0; k < nq; ++k)
+        two_rounds = two_rounds || (resident ? resident->windows[idx[k]].min_known
+                                             : csm_host_min_known(pp[k].n, spec.known_thr)) > 1;
     for (int k = 0; k < nq; ++k) {
         BatchPrep& p = pp[k];
         /* lists and records per slice, or per pair of slices (2 n entries each) */
