@@ -118,3 +118,31 @@ def test_many_beams_joint_and_fallback(ctx, oracle, n_beams, expect_bound_pass):
     final, (scored, skipped) = _run(ctx, case, rx, ry, rt, Lr, n_copies=2)
     assert all(f == _want(oracle, case, rx, ry, rt, Lr) for f in final)
     assert (skipped > 0) == expect_bound_pass
+
+
+def test_thresholded_correlative_batch_uses_two_rounds(ctx, oracle):
+    """LoopDetectorCorrelative's thresholds (score 0.55, known rate 0.6, launcher_settings_default.json:
+    69-70): the coarse node's known count decides eligibility, the exact pass runs in two rounds behind
+    the bound pass, and the records equal the literal sweep's."""
+    qs, cases = [], []
+    for i, seed in enumerate([91, 92, 93, 94, 95, 96]):
+        case = synth.csm_case(seed, n_beams=1080, fov=1.5 * math.pi, init_error=(0.25, -0.2, 0.03))
+        cases.append(case)
+        qs.append(dict(map_id=1400 + i, geom=case["geom"], angles=case["angles"], ranges=case["ranges"],
+                       rel_pose=case["rel_pose"], init_pose=case["init_pose"]))
+        ctx.upload_grid(1400 + i, case["grid"])
+    rx, ry, rt, Lr = 2.0, 2.0, math.radians(20), 4
+    ctx.bound_pass_stats()
+    outs = ctx.correlative_match_batch(qs, rx, ry, rt, Lr, 0.55, 0.6)
+    scored, skipped = ctx.bound_pass_stats()
+    assert skipped > scored > 0
+    for c, o in zip(cases, outs):
+        want = oracle.csm(c, rx, ry, rt, Lr, 0.55, 0.6)
+        assert o["pose_found"] == want["found"]
+        if want["found"]:
+            assert (o["raw"]["best_x"], o["raw"]["best_y"], o["raw"]["best_theta"]) == \
+                (want["bestX"], want["bestY"], want["bestT"])
+            assert o["raw"]["score"] == want["scoreMax"]
+        assert o["estimated_pose"] == want["estimatedPose"]
+    for q in qs:
+        ctx.release_grid(q["map_id"])
