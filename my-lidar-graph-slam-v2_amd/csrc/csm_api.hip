@@ -1,5 +1,8 @@
-/* csm_api.hip -- host side of libcsm_hip.so: the C ABI of include/csm_hip.h on
- * top of the gfx950 kernels in csm_kernels.hip. One translation unit.
+/* csm_api.hip -- host side of the matchers in libcsm_hip.so: the C ABI of include/csm_hip.h
+ * (planner, batch staging, graph replay) on top of the gfx950 kernels. No device code here:
+ * the kernels are launched through csm_launch.hpp (per-slice kernels, csm_kernels.hip),
+ * csm_joint.hpp (batched fine level) and csm_phase.hpp (coarse-first search), each a
+ * translation unit of its own, so an edit of the host logic recompiles in seconds.
  *
  * Host-side expressions that must agree bit for bit with the reference
  * (search step, window, projection, pose algebra) are restated here from the
@@ -7,7 +10,7 @@
  */
 #include "csm_internal.hpp"
 
-#include "csm_kernels.hip"
+#include "csm_launch.hpp"
 #include "csm_joint.hpp"
 #include "csm_phase.hpp"
 
@@ -462,98 +465,34 @@ int make_plan(csm_ctx* ctx, const DeviceGrid& g, const csm_window* w, Plan* p)
     return CSM_OK;
 }
 
-/* Dynamic LDS above 64 KB needs the function attribute. It is a driver call and
- * it belongs to the function on a device, not to a context: one process-wide
- * table, only ever raised (a smaller value set by another context would make
- * a larger launch of this one fail). */
-template <typename K>
-int set_lds(csm_ctx* ctx, K kernel, size_t bytes)
+/* What the wrappers of csm_launch.hip return: a HIP error code, or -1 for "no kernel instantiated". */
+int launched_ok(csm_ctx* ctx, int e, const char* what)
 {
-    if (bytes <= 64 * 1024)
-        return CSM_OK;
-    static std::mutex guard;
-    static std::map<std::pair<int, const void*>, size_t> granted;
-    const void* fn = reinterpret_cast<const void*>(kernel);
-    std::lock_guard<std::mutex> lock(guard);
-    size_t& have = granted[{ ctx->device, fn }];
-    if (bytes > have) {
-        HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        have = bytes;
-    }
+    if (e < 0)
+        return fail(ctx, CSM_EINVAL, "internal: no %s kernel for this launch shape", what);
+    if (e != 0)
+        return fail(ctx, CSM_EIO, "%s kernel launch failed: %s", what, hipGetErrorString((hipError_t)e));
     return CSM_OK;
 }
 
-/* Template dispatch of the strided kernels (coarser levels): LSTRIDE in {128,192} x R in {1,2,4},
- * stride a power of two (MODE 1) or any (MODE 2). The stride-1 level is always a pair kernel
- * (PAIR_DISPATCH); round 1's stride-1 body survives only as the arg-max pass (k_argmax). */
-#define SCORE_CASE(LS, RR, ST, CALL)                                                   \
-    if (pp.lstride == LS && pp.R == RR && mode == ST) {                                \
-        if (pp.weighted || ST != 0) {                                                  \
-            CALL(LS, RR, ST, true);                                                    \
-        } else {                                                                       \
-            CALL(LS, RR, ST, false);                                                   \
-        }                                                                              \
-        launched = true;                                                               \
-    }
-#ifdef CSM_FAST_BUILD
-/* tuning builds (tools/build_variant.sh): only the instantiations bench.py's configs[1] uses */
-#define SCORE_DISPATCH(CALL)                                                           \
-    do {                                                                               \
-        SCORE_CASE(192, 1, 1, CALL)                                                    \
-    } while (0)
-#else
-#define SCORE_DISPATCH(CALL)                                                           \
-    do {                                                                               \
-        SCORE_CASE(128, 1, 1, CALL) SCORE_CASE(128, 2, 1, CALL)                        \
-        SCORE_CASE(128, 4, 1, CALL) SCORE_CASE(192, 1, 1, CALL)                        \
-        SCORE_CASE(192, 2, 1, CALL) SCORE_CASE(192, 4, 1, CALL)                        \
-        SCORE_CASE(128, 1, 2, CALL) SCORE_CASE(128, 2, 2, CALL)                        \
-        SCORE_CASE(128, 4, 2, CALL) SCORE_CASE(192, 1, 2, CALL)                        \
-        SCORE_CASE(192, 2, 2, CALL) SCORE_CASE(192, 4, 2, CALL)                        \
-    } while (0)
-#endif
-
-#define CALL_SINGLE(LS, RR, ST, WW)                                                    \
-    do {                                                                               \
-        int rc_ = set_lds(ctx, k_score<LS, RR, ST, WW>, lds);                          \
-        if (rc_)                                                                       \
-            return rc_;                                                                \
-        hipLaunchKernelGGL((k_score<LS, RR, ST, WW>), grid, dim3(kBlock), lds, ctx->stream, \
-                           job, pp.cbx, pp.groups, n_buf);                             \
-    } while (0)
-
-#define CALL_BATCH(LS, RR, ST, WW)                                                     \
-    do {                                                                               \
-        int rc_ = set_lds(ctx, k_score_batch<LS, RR, ST, WW>, lds);                    \
-        if (rc_)                                                                       \
-            return rc_;                                                                \
-        hipLaunchKernelGGL((k_score_batch<LS, RR, ST, WW>), grid, dim3(kBlock), lds,   \
-                           ctx->stream, jobs_dev, pp.cbx, pp.groups, n_slices, n_buf); \
-    } while (0)
-
-#define PAIR_CASE_R(LS, RR, CALL)                                                      \
-    if (pp.lstride == LS && pp.R == RR) {                                              \
-        if (pp.weighted) {                                                             \
-            CALL(LS, RR, true);                                                        \
-        } else {                                                                       \
-            CALL(LS, RR, false);                                                       \
-        }                                                                              \
-        launched = true;                                                               \
-    }
-#define PAIR_CASE(LS, CALL) PAIR_CASE_R(LS, 8, CALL) PAIR_CASE_R(LS, 6, CALL)
-#ifdef CSM_FAST_BUILD
-#define PAIR_DISPATCH(CALL)                                                            \
-    do {                                                                               \
-        PAIR_CASE(150, CALL) PAIR_CASE(156, CALL)                                      \
-    } while (0)
-#else
-#define PAIR_DISPATCH(CALL)                                                            \
-    do {                                                                               \
-        PAIR_CASE(86, CALL) PAIR_CASE(98, CALL) PAIR_CASE(118, CALL) PAIR_CASE(124, CALL) \
-        PAIR_CASE(130, CALL) PAIR_CASE(150, CALL) PAIR_CASE(156, CALL) PAIR_CASE(162, CALL) \
-        PAIR_CASE(182, CALL)                                                           \
-    } while (0)
-#endif
+/* the fields of a csm_launch::ScoreLaunch a pass plan decides */
+csm_launch::ScoreLaunch score_launch(const csm_ctx* ctx, const PassPlan& pp, dim3 grid, size_t lds)
+{
+    csm_launch::ScoreLaunch a;
+    a.stream = ctx->stream;
+    a.device = ctx->device;
+    a.lstride = pp.lstride;
+    a.R = pp.R;
+    a.mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
+    a.weighted = pp.weighted;
+    a.lists = pp.lists;
+    a.cbx = pp.cbx;
+    a.groups = pp.groups;
+    a.grid = grid;
+    a.lds = lds;
+    a.ncb = pp.ncb();
+    return a;
+}
 
 /* Which candidate (lane group g, column dxi) a thread of a pair kernel owns. A ds_read_b64
  * serves a half-wave in one pass when its 32 slots cover the 64 banks once; slot (g, dxi) of an
@@ -651,39 +590,10 @@ int lane_map_for(csm_ctx* ctx, const PassPlan& pp, const uint16_t** out)
     return CSM_OK;
 }
 
-#define CALL_PAIRS_SINGLE(LS, RR, WW)                                                  \
-    do {                                                                               \
-        int rc_ = set_lds(ctx, k_score_pairs<LS, RR, WW>, lds);                        \
-        if (rc_)                                                                       \
-            return rc_;                                                                \
-        hipLaunchKernelGGL((k_score_pairs<LS, RR, WW>), theta_major ? dim3(grid.y, grid.x, 1) : grid, \
-                           dim3(kBlock), lds, ctx->stream, job, pp.cbx, pp.groups, theta_major, lane_map); \
-    } while (0)
-
-#define CALL_PAIRS_BATCH(LS, RR, WW)                                                   \
-    do {                                                                               \
-        if (pp.lists == 2) {                                                           \
-            int rc_ = set_lds(ctx, k_score_pairs2_batch<LS, RR, WW>, lds);             \
-            if (rc_)                                                                   \
-                return rc_;                                                            \
-            hipLaunchKernelGGL((k_score_pairs2_batch<LS, RR, WW>),                     \
-                               dim3(grid.x, (grid.y + 1) / 2, grid.z), dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map, bb); \
-        } else {                                                                       \
-            int rc_ = set_lds(ctx, k_score_pairs_batch<LS, RR, WW>, lds);              \
-            if (rc_)                                                                   \
-                return rc_;                                                            \
-            hipLaunchKernelGGL((k_score_pairs_batch<LS, RR, WW>), grid, dim3(kBlock), lds, \
-                               ctx->stream, jobs_dev, pp.cbx, pp.groups, lane_map, xcd_map, bb); \
-        }                                                                              \
-    } while (0)
-
 int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_theta, int n_slices)
 {
     const dim3 grid(pp.ncb(), n_theta, n_slices);
     if (pp.pairs) {
-        const size_t lds = pass_lds_bytes(pp);
-        bool launched = false;
         /* a launch far larger than the chip, not tile-split: slices fastest (see k_score_pairs) */
         int theta_major = (n_slices == 1 && (long)pp.ncb() * n_theta >= 4096 && pp.ncb() <= 65535) ? 1 : 0;
         if (ctx->tune.theta_major >= 0)
@@ -693,34 +603,19 @@ int launch_score(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, int n_th
         const uint16_t* lane_map = nullptr;
         if (int rc = lane_map_for(ctx, pp, &lane_map))
             return rc;
-        PAIR_DISPATCH(CALL_PAIRS_SINGLE);
-        if (!launched)
-            return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
-        HIP_TRY(ctx, hipGetLastError());
-        return CSM_OK;
+        csm_launch::ScoreLaunch a = score_launch(ctx, pp, grid, pass_lds_bytes(pp));
+        a.theta_major = theta_major;
+        a.lane_map = lane_map;
+        return launched_ok(ctx, csm_launch::score_pairs(a, job), "pair-row score");
     }
-    const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
     size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
     const int n_buf = pick_buffers(ctx->tune, lds, (long)grid.x * grid.y * grid.z);
-    lds *= n_buf;
-    bool launched = false;
-    SCORE_DISPATCH(CALL_SINGLE);
-    if (!launched)
-        return fail(ctx, CSM_EINVAL, "internal: no kernel for lstride %d R %d", pp.lstride, pp.R);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    csm_launch::ScoreLaunch a = score_launch(ctx, pp, grid, lds * n_buf);
+    a.n_buf = n_buf;
+    return launched_ok(ctx, csm_launch::score_strided(a, job), "strided score");
 }
-
-#define CALL_PAIRS_LIST(LS, RR, WW)                                                    \
-    do {                                                                               \
-        int rc_ = set_lds(ctx, k_score_pairs_list<LS, RR, WW>, lds);                   \
-        if (rc_)                                                                       \
-            return rc_;                                                                \
-        hipLaunchKernelGGL((k_score_pairs_list<LS, RR, WW>), dim3(blocks), dim3(kBlock), lds, ctx->stream, job, \
-                           pp.cbx, pp.groups, pp.ncb(), lane_map, items, count);       \
-    } while (0)
 
 /* the single-window pair kernel over a work list of (slice, candidate block) items */
 int launch_score_list(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, const uint32_t* items,
@@ -728,39 +623,23 @@ int launch_score_list(csm_ctx* ctx, const ScoreJob& job, const PassPlan& pp, con
 {
     if (!pp.pairs)
         return fail(ctx, CSM_EINVAL, "internal: list launches need the pair kernel");
-    const size_t lds = pass_lds_bytes(pp);
-    bool launched = false;
     const uint16_t* lane_map = nullptr;
     if (int rc = lane_map_for(ctx, pp, &lane_map))
         return rc;
-    PAIR_DISPATCH(CALL_PAIRS_LIST);
-    if (!launched)
-        return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d", pp.lstride);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    csm_launch::ScoreLaunch a = score_launch(ctx, pp, dim3(blocks), pass_lds_bytes(pp));
+    a.lane_map = lane_map;
+    a.items = items;
+    a.count = count;
+    a.blocks = blocks;
+    return launched_ok(ctx, csm_launch::score_pairs_list(a, job), "pair-row list");
 }
-
-#define ARGMAX_CASE(LS, RR)                                                            \
-    if (pp.lstride == LS && pp.R == RR) {                                              \
-        hipLaunchKernelGGL((k_argmax<LS, RR>), grid, dim3(kBlock), 0, ctx->stream, job, \
-                           pp.cbx, pp.groups);                                         \
-        launched = true;                                                               \
-    }
 
 int launch_argmax(csm_ctx* ctx, const ScoreJob& job, const PassPlan& plan, int n_theta)
 {
     /* only the lane <-> candidate mapping (cbx, groups, R) matters to this pass:
      * a pair plan borrows the R = 8 instantiation of the plain kernel */
-    PassPlan pp = plan;
-    if (pp.pairs)
-        pp.lstride = 128;        /* k_argmax<128, 6 | 8> exist */
-    const dim3 grid(pp.ncb(), n_theta, 1);
-    bool launched = false;
-    ARGMAX_CASE(128, 8) ARGMAX_CASE(128, 6)
-    if (!launched)
-        return fail(ctx, CSM_EINVAL, "internal: no arg-max kernel for lstride %d R %d", pp.lstride, pp.R);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    const csm_launch::ScoreLaunch a = score_launch(ctx, plan, dim3(plan.ncb(), n_theta, 1), 0);
+    return launched_ok(ctx, csm_launch::argmax(a, job), "arg-max");     /* k_argmax<128, 6 | 8> exist */
 }
 
 /* One launch of the pair kernels over row blocks [first block of `pp`'s numbering ...) of a batch. */
@@ -783,7 +662,6 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
                        const JointList* list = nullptr, int which = 0)
 {
     const size_t lds = pass_lds_bytes(pp);
-    bool launched = false;
     const uint16_t* lane_map = nullptr;
     if (int rc = lane_map_for(ctx, pp, &lane_map))
         return rc;
@@ -818,11 +696,11 @@ int launch_pairs_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, const PassPlan& p
             return fail(ctx, CSM_EIO, "joint fine kernel launch failed: %s", hipGetErrorString((hipError_t)e));
         return CSM_OK;
     }
-    PAIR_DISPATCH(CALL_PAIRS_BATCH);
-    if (!launched)
-        return fail(ctx, CSM_EINVAL, "internal: no pair kernel for LS %d R %d", pp.lstride, pp.R);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    csm_launch::ScoreLaunch a = score_launch(ctx, pp, grid, lds);
+    a.lane_map = lane_map;
+    a.xcd_map = xcd_map;
+    a.bb = bb;
+    return launched_ok(ctx, csm_launch::score_pairs_batch(a, jobs_dev), "pair-row batch");
 }
 
 int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const PassPlan& pp,
@@ -855,18 +733,14 @@ int launch_score_batch(csm_ctx* ctx, const ScoreJob* jobs_dev, int n_jobs, const
         return launch_pairs_batch(ctx, jobs_dev, tail, dim3(pp.ncbx, grid.y, grid.z),
                                   BlockBase{ (pp.ncby - 1) * cby, pp.ncbx * (pp.ncby - 1), pp.ncb() }, list, 1);
     }
-    const int mode = pp.stride == 1 ? 0 : pp.log2s >= 0 ? 1 : 2;
     size_t lds = pass_lds_bytes(pp);
     if (lds > 160 * 1024 - 256)
         return fail(ctx, CSM_EINVAL, "internal: LDS region too large");
     const int n_buf = pick_buffers(ctx->tune, lds, (long)grid.x * grid.y * grid.z);
-    lds *= n_buf;
-    bool launched = false;
-    SCORE_DISPATCH(CALL_BATCH);
-    if (!launched)
-        return fail(ctx, CSM_EINVAL, "internal: no kernel for lstride %d R %d", pp.lstride, pp.R);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    csm_launch::ScoreLaunch a = score_launch(ctx, pp, grid, lds * n_buf);
+    a.n_buf = n_buf;
+    a.n_slices = n_slices;
+    return launched_ok(ctx, csm_launch::score_strided_batch(a, jobs_dev), "strided batch");
 }
 
 
@@ -905,10 +779,11 @@ int launch_box_jobs(csm_ctx* ctx, const std::vector<PendingBox>& pending)
     ScopedTimer tm(ctx, "boxmax");
     for (size_t first = 0; first < pending.size(); first += 65535) {      /* grid.z limit */
         const unsigned nz = (unsigned)std::min<size_t>(65535, pending.size() - first);
-        hipLaunchKernelGGL(k_boxmax_batch, dim3(ceil_div(pitch_max, kBoxTC), ceil_div(rows_max, kBoxTR), nz),
-                           dim3(256), 0, ctx->stream, reinterpret_cast<const BoxJob*>(ctx->box_jobs.p) + first);
+        const int e = csm_launch::boxmax_batch(ctx->stream, dim3(ceil_div(pitch_max, kBoxTC), ceil_div(rows_max, kBoxTR), nz),
+                                               reinterpret_cast<const BoxJob*>(ctx->box_jobs.p) + first);
+        if (e)
+            return launched_ok(ctx, e, "box-maximum");
     }
-    HIP_TRY(ctx, hipGetLastError());
     return CSM_OK;
 }
 
@@ -1005,9 +880,9 @@ int ensure_xgrid(csm_ctx* ctx, DeviceGrid& g, int need_pad)
     const size_t total = (size_t)prows * xp;
     const int blocks = (int)std::min<size_t>(4096, (total + 255) / 256);
     ScopedTimer tm(ctx, "expand");
-    hipLaunchKernelGGL(k_expand_pairs, dim3(blocks), dim3(256), 0, ctx->stream, g.levels[0].cells, g.rows,
-                       g.cols, g.pitch, reinterpret_cast<uint2*>(g.xg), prows, xp, pad);
-    HIP_TRY(ctx, hipGetLastError());
+    if (int rc = launched_ok(ctx, csm_launch::expand_pairs(ctx->stream, blocks, g.levels[0].cells, g.rows, g.cols, g.pitch,
+                                                            g.xg, prows, xp, pad), "pair-row copy"))
+        return rc;
     g.xg_pad = pad;
     g.xg_pitch = xp;
     g.xg_stale = false;
@@ -1166,10 +1041,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     }
     {
         const size_t lds = bin_lds_bytes(p.tiles_x * p.tiles_y, p.n);
-        if ((rc = set_lds(ctx, k_bin, lds))) return rc;
         ScopedTimer tm(ctx, "bin");
-        hipLaunchKernelGGL(k_bin, dim3(p.n_theta), dim3(kBinBlock), lds, ctx->stream, bj);
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launched_ok(ctx, csm_launch::bin(ctx->stream, ctx->device, p.n_theta, lds, bj), "binning"))) return rc;
     }
     if (p.L > 1 && tp_mode != 2) {
         /* the coarse pass accumulates with atomics: its sums are cleared first, but
@@ -1182,8 +1055,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         zj.always = coarse_exits ? 0 : 1;
         zj.pad = 0;
         const int zb = (int)std::min<size_t>(256, (zj.words + 255) / 256);
-        hipLaunchKernelGGL(k_zero_if_band, dim3(std::max(1, zb), 1), dim3(256), 0, ctx->stream, zj);
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launched_ok(ctx, csm_launch::zero_if_band(ctx->stream, std::max(1, zb), zj), "edge-band clear"))) return rc;
     }
 
     ScoreJob base;
@@ -1388,10 +1260,8 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     fin.out = out_dev;
     {
         const size_t lds = (size_t)p.n * 8;
-        if ((rc = set_lds(ctx, k_finalize, lds))) return rc;
         ScopedTimer tm(ctx, "finalize");
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), lds, ctx->stream, fin);
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launched_ok(ctx, csm_launch::finalize(ctx->stream, ctx->device, lds, fin), "finalize"))) return rc;
     }
     return CSM_OK;
 }
@@ -1551,11 +1421,7 @@ int resolve_ties(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p
     if (n == 0)
         return CSM_OK;
     const size_t lds = (size_t)p.n * 8;
-    if ((rc = set_lds(ctx, k_tie_replay, lds))) return rc;
-    hipLaunchKernelGGL(k_tie_replay, dim3(n), dim3(kBlock), lds, ctx->stream, tj);
-    hipLaunchKernelGGL(k_tie_pick, dim3(1), dim3(64), 0, ctx->stream, tj);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    return launched_ok(ctx, csm_launch::tie_replay_pick(ctx->stream, ctx->device, (unsigned)n, lds, tj), "tie replay");
 }
 
 /* The reference's sequential sweep over device-computed exact scores: used
@@ -1590,8 +1456,8 @@ int resolve_literal(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan
     cj.stride = p.L;
     cj.out_score = reinterpret_cast<double*>(ctx->ex_coarse.p);
     cj.out_k = reinterpret_cast<uint32_t*>(ctx->ex_coarse_k.p);
-    hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((nc + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       ctx->stream, cj);
+    if (int e = csm_launch::exact_scores(ctx->stream, (unsigned)((nc + kBlock - 1) / kBlock), cj))
+        return launched_ok(ctx, e, "exact score");
     ExactJob fj = ej;
     fj.cells = g.levels[0].cells;
     fj.nx = p.nx;
@@ -1599,8 +1465,8 @@ int resolve_literal(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan
     fj.stride = 1;
     fj.out_score = reinterpret_cast<double*>(ctx->ex_fine.p);
     fj.out_k = reinterpret_cast<uint32_t*>(ctx->ex_fine_k.p);
-    hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       ctx->stream, fj);
+    if (int e = csm_launch::exact_scores(ctx->stream, (unsigned)((nf + kBlock - 1) / kBlock), fj))
+        return launched_ok(ctx, e, "exact score");
     LiteralJob lj;
     std::memset(&lj, 0, sizeof(lj));
     lj.coarse_score = cj.out_score;
@@ -1616,9 +1482,7 @@ int resolve_literal(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan
     lj.min_known = w->min_known;
     lj.score_thr = w->score_threshold;
     lj.out = out_dev;
-    hipLaunchKernelGGL(k_csm_literal_scan, dim3(1), dim3(64), 0, ctx->stream, lj);
-    HIP_TRY(ctx, hipGetLastError());
-    return CSM_OK;
+    return launched_ok(ctx, csm_launch::literal_scan(ctx->stream, lj), "literal sweep");
 }
 
 /* Finish a window whose fast-path record carries a tie or an edge-band flag. */
@@ -1917,11 +1781,10 @@ int csm_upload_grid_blocks(csm_ctx* ctx, uint64_t map_id, const uint16_t* const*
     char* d_stage = reinterpret_cast<char*>(ctx->scratch.p);
     HIP_TRY(ctx, hipMemcpyAsync(d_stage, ctx->pin, stage_bytes, hipMemcpyHostToDevice, ctx->stream));
     const int grid_blocks = (int)std::min<size_t>(4096, ((size_t)rows * g.pitch + 255) / 256);
-    hipLaunchKernelGGL(k_deblock, dim3(grid_blocks), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const uint16_t*>(d_stage + head), reinterpret_cast<const int32_t*>(d_stage) + 2,
-                       log2_block, block_cols, rows, cols, g.pitch, base.cells, g.alloc, n_blocks,
-                       reinterpret_cast<int32_t*>(d_stage));
-    HIP_TRY(ctx, hipGetLastError());
+    if (int e = csm_launch::deblock(ctx->stream, grid_blocks, reinterpret_cast<const uint16_t*>(d_stage + head),
+                                    reinterpret_cast<const int32_t*>(d_stage) + 2, log2_block, block_cols, rows, cols,
+                                    g.pitch, base.cells, g.alloc, n_blocks, reinterpret_cast<int32_t*>(d_stage)))
+        return launched_ok(ctx, e, "block upload");
     int32_t known[2] = { rows, cols };
     HIP_TRY(ctx, hipMemcpyAsync(known, d_stage, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2320,9 +2183,9 @@ int csm_correlative_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
         {
             ScopedTimer tm(ctx, "project");
             const int pb = ceil_div(n, kBlock);
-            hipLaunchKernelGGL(k_project_batch, dim3(pb, proj_theta_groups(w.n_theta, pb), 1), dim3(kBlock), 0,
-                               ctx->stream, reinterpret_cast<const ProjJob*>(qd));
-            HIP_TRY(ctx, hipGetLastError());
+            if (int e = csm_launch::project_batch(ctx->stream, dim3(pb, proj_theta_groups(w.n_theta, pb), 1),
+                                                  reinterpret_cast<const ProjJob*>(qd)))
+                return launched_ok(ctx, e, "projection");
         }
         int rc2 = search_window(ctx, *g, &w, p, col_dev, row_dev, res_dev);
         if (rc2)
@@ -2531,9 +2394,8 @@ int bnb_literal(csm_ctx* ctx, const csm_loop_query& q, const BatchPrep& p, const
         ej.lut = ctx->lut_dev;
         ej.out_score = reinterpret_cast<double*>(ctx->ex_fine.p);
         ej.out_k = reinterpret_cast<uint32_t*>(ctx->ex_fine_k.p);
-        hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
-                           0, ctx->stream, ej);
-        HIP_TRY(ctx, hipGetLastError());
+        if (int e = csm_launch::exact_scores(ctx->stream, (unsigned)((n + kBlock - 1) / kBlock), ej))
+            return launched_ok(ctx, e, "exact score");
         sc[h].resize(n);
         kn[h].resize(n);
         HIP_TRY(ctx, hipMemcpyAsync(sc[h].data(), ej.out_score, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -3124,9 +2986,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     if (!resident) {
         ScopedTimer tm(ctx, "project");
         const int pb = ceil_div(n_points_max, kBlock);
-        hipLaunchKernelGGL(k_project_batch, dim3(pb, proj_theta_groups(n_theta_max, (long)pb * nq), nq),
-                           dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ProjJob*>(d_ij));
-        HIP_TRY(ctx, hipGetLastError());
+        if (int e = csm_launch::project_batch(ctx->stream, dim3(pb, proj_theta_groups(n_theta_max, (long)pb * nq), nq),
+                                              reinterpret_cast<const ProjJob*>(d_ij)))
+            return launched_ok(ctx, e, "projection");
     }
     if (joint) {
         ScopedTimer tm(ctx, "bin");
@@ -3135,17 +2997,16 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         if (e != 0)
             return fail(ctx, CSM_EIO, "joint binning launch failed: %s", hipGetErrorString((hipError_t)e));
     } else {
-        if ((rc = set_lds(ctx, k_bin_batch, bin_lds))) return rc;
         ScopedTimer tm(ctx, "bin");
-        hipLaunchKernelGGL(k_bin_batch, dim3(n_theta_max, nq), dim3(kBinBlock), bin_lds, ctx->stream,
-                           reinterpret_cast<const BinJob*>(d_bj));
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launched_ok(ctx, csm_launch::bin_batch(ctx->stream, ctx->device, n_theta_max, nq, bin_lds,
+                                                         reinterpret_cast<const BinJob*>(d_bj)), "binning")))
+            return rc;
     }
     if (H > 0) {
         const int zb = (int)std::min<size_t>(64, (zero_words_max + 255) / 256);
-        hipLaunchKernelGGL(k_zero_if_band_batch, dim3(std::max(1, zb), nq * H), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const ZeroJob*>(d_zj));
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launched_ok(ctx, csm_launch::zero_if_band_batch(ctx->stream, std::max(1, zb), nq * H,
+                                                                  reinterpret_cast<const ZeroJob*>(d_zj)), "edge-band clear")))
+            return rc;
     }
     for (int h = H; h >= 1; --h) {
         /* keep >= ~2k workgroups in flight: split the tile list when the
@@ -3172,14 +3033,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     }
     auto finalize = [&]() -> int {
         const size_t lds = (size_t)n_points_max * 8;
-        int rc2 = set_lds(ctx, k_finalize_batch, lds);
-        if (rc2)
-            return rc2;
         ScopedTimer tm(ctx, "finalize");
-        hipLaunchKernelGGL(k_finalize_batch, dim3(nq), dim3(kBlock), lds, ctx->stream,
-                           reinterpret_cast<const FinalJob*>(d_fj));
-        HIP_TRY(ctx, hipGetLastError());
-        return CSM_OK;
+        return launched_ok(ctx, csm_launch::finalize_batch(ctx->stream, ctx->device, nq, lds,
+                                                           reinterpret_cast<const FinalJob*>(d_fj)), "finalize");
     };
     if (bound_pass) {
         size_t blocks_total = 0;
@@ -3235,9 +3091,9 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     /* device copy of the records in query order (csm_copy_last_batch_records) */
     csm_result* rec_dev = reinterpret_cast<csm_result*>(ctx->rec_dev.p);
     if (rec_dev) {
-        hipLaunchKernelGGL(k_scatter_records, dim3(ceil_div(nq, 256)), dim3(256), 0, ctx->stream, d_out,
-                           reinterpret_cast<const int32_t*>(d_idx), rec_dev, nq);
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launched_ok(ctx, csm_launch::scatter_records(ctx->stream, d_out, reinterpret_cast<const int32_t*>(d_idx),
+                                                               rec_dev, nq), "record scatter")))
+            return rc;
     }
     tick("launch");
     std::vector<csm_result> res(nq);
@@ -3553,10 +3409,9 @@ int csm_grid_search_match(csm_ctx* ctx, uint64_t map_id, const csm_geometry* geo
         const unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock);
         {
             ScopedTimer tm(ctx, "grid_search");
-            hipLaunchKernelGGL(k_grid_scores, dim3(blocks), dim3(kBlock), 0, ctx->stream, gj);
-            hipLaunchKernelGGL(k_grid_pick, dim3(blocks), dim3(kBlock), 0, ctx->stream, gj);
+            if (int e = csm_launch::grid_scores_pick(ctx->stream, blocks, gj))
+                return launched_ok(ctx, e, "grid search");
         }
-        HIP_TRY(ctx, hipGetLastError());
         unsigned long long best[2] = { 0, 0 };
         HIP_TRY(ctx, hipMemcpyAsync(best, d_best, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -3701,9 +3556,8 @@ int csm_project_scan(csm_ctx* ctx, const csm_geometry* geom, const double sensor
     pj.off_x = geom->offset_x;
     pj.off_y = geom->offset_y;
     pj.res = geom->resolution;
-    hipLaunchKernelGGL(k_project, dim3(ceil_div(n, kBlock), proj_theta_groups(n_theta, ceil_div(n, kBlock))),
-                       dim3(kBlock), 0, ctx->stream, pj);
-    HIP_TRY(ctx, hipGetLastError());
+    if (int e = csm_launch::project(ctx->stream, dim3(ceil_div(n, kBlock), proj_theta_groups(n_theta, ceil_div(n, kBlock))), pj))
+        return launched_ok(ctx, e, "projection");
     uint32_t count = 0;
     HIP_TRY(ctx, hipMemcpyAsync(hit_col, col_dev, hn * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(hit_row, row_dev, hn * 4, hipMemcpyDeviceToHost, ctx->stream));

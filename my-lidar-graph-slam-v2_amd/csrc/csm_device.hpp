@@ -24,6 +24,19 @@ constexpr int kMaxElig = 8;      /* eligibility levels per scoring job */
  * band of a coarser level for some candidate offset */
 constexpr uint32_t kFlagBandTouch = 1u << 16;
 
+constexpr int kBoxTR = 32, kBoxTC = 64, kBoxMaxWin = 64;    /* k_boxmax_batch: output tile, largest window */
+constexpr int kProjSlices = 256;     /* k_project: theta slices per workgroup (LDS table) */
+constexpr int kBinDebugRows = 65536; /* -DCSM_BIN_TIMING builds: rows of k_bin's phase counters */
+
+/* Where a pair-kernel launch sits among the candidate blocks of its window: a window's last
+ * row block may be a launch of its own with fewer rows per lane (R = 6 for 36 rows instead of
+ * R = 8 with a quarter of the lanes' rows outside the window: launch_score_batch). */
+struct BlockBase {
+    int row_base;       /* first candidate row of this launch's row block 0 */
+    int cb_base;        /* this launch's block 0 in the window's numbering (BlockBest slots) */
+    int ncb;            /* candidate blocks of the window, all launches */
+};
+
 /* One non-empty endpoint tile of one theta slice. */
 struct TileRec {
     int32_t  r0, c0;     /* grid row / col of the first cell of the tile's

@@ -42,7 +42,6 @@ namespace csm {
 /* tuning builds only: cycles per phase of k_bin, one row of 8 counters per workgroup
  * (thread 0, plain stores); the host points BinJob.tuning_counters at
  * kBinDebugRows rows */
-constexpr int kBinDebugRows = 65536;
 #define BIN_TICK(k)                                                                   \
     do {                                                                              \
         if (threadIdx.x == 0 && job.tuning_counters) {                                         \
@@ -1400,7 +1399,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_pairs2_batch(const ScoreJob
  * 64 + W - 1, staged in LDS; vertical maxima into a second LDS array, then
  * horizontal maxima to memory. Pad columns (cols..pitch) are written 0.
  * grid = (column tiles, row tiles, jobs). */
-constexpr int kBoxTR = 32, kBoxTC = 64, kBoxMaxWin = 64;
 
 __global__ __launch_bounds__(256) void k_boxmax_batch(const BoxJob* jobs)
 {
@@ -1886,7 +1884,6 @@ __global__ __launch_bounds__(256) void k_scatter_records(const csm_result* src, 
  *   rounds theta_t and arg, the device rounds B)      -> 4e-16 * (|theta| + |D| + |a|)
  *   device libm <= 3 ulp on each of cosB, sinB, cosD, sinD, two products, one sum
  *                                                     -> 2.4e-15 */
-constexpr int kProjSlices = 256;     /* slices per workgroup (LDS table) */
 
 __device__ __forceinline__ void proj_body(const ProjJob& job)
 {

@@ -265,14 +265,6 @@ __device__ __forceinline__ void lds_wait(unsigned long long (&q)[N])
 }
 
 
-/* Where a pair-kernel launch sits among the candidate blocks of its window: a window's last
- * row block may be a launch of its own with fewer rows per lane (R = 6 for 36 rows instead of
- * R = 8 with a quarter of the lanes' rows outside the window: launch_score_batch). */
-struct BlockBase {
-    int row_base;       /* first candidate row of this launch's row block 0 */
-    int cb_base;        /* this launch's block 0 in the window's numbering (BlockBest slots) */
-    int ncb;            /* candidate blocks of the window, all launches */
-};
 
 /* Inclusive prefix sum over the wave's 64 lanes, data-parallel primitives only (no LDS
  * traffic: the gather counts its own LDS reads in lgkmcnt). */
