@@ -2582,11 +2582,11 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
     size_t binj_lds = 0;
     for (int k = 0; k < nq; ++k)
         binj_lds = std::max(binj_lds, csm::binj_lds_bytes(pp[k].tiles_x * pp[k].tiles_y, pp[k].n,
-                                                          bin_hash_size(2 * pp[k].n)));
+                                                          csm::binj_hash_size(pp[k].n)));
     const bool joint = ctx->tune.joint && lp[0].pairs && lp[0].lists == 2 && lp[0].weighted &&
-                       binj_lds <= 150 * 1024;     /* up to ~1,365 beams two binning workgroups share a CU; above
-                                                      that one (the fine level's gain outweighs the slower binning),
-                                                      up to ~5,400 beams per scan */
+                       binj_lds <= 150 * 1024;     /* up to ~1,100 beams four binning workgroups share a CU, two up
+                                                      to ~2,200; one (the fine level's gain outweighs the slower
+                                                      binning) up to ~4,200 beams per scan */
     lp[0].joint = joint;
     /* The packed-fp32 bound pass in front of the exact kernel: only where the arg-max is over ALL
      * candidates of the window -- the correlative sweep with a known-rate threshold that the coarse
@@ -2802,7 +2802,7 @@ int run_batch_group(csm_ctx* ctx, const csm_loop_query* queries, const std::vect
         B.tiles_y = p.tiles_y;
         B.known_r0 = g.known_r0;
         B.known_c0 = g.known_c0;
-        B.hash_size = bin_hash_size(joint ? 2 * p.n : p.n);
+        B.hash_size = joint ? csm::binj_hash_size(p.n) : bin_hash_size(p.n);
         B.max_mult = lp[0].weighted ? kMaxMult : 1;
         B.lstride = lstride;
         B.pair_mode = joint ? 2 : lp[0].pairs ? 1 : 0;

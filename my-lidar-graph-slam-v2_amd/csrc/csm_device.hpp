@@ -86,7 +86,8 @@ struct BinJob {
     int32_t x_lo, y_lo;        /* most negative candidate offset */
     int32_t x_hi, y_hi;        /* most positive candidate offset */
     int32_t tiles_x, tiles_y;
-    int32_t hash_size;         /* power of two >= 4/3 n_points (LDS hash table of k_bin) */
+    int32_t hash_size;         /* slots of the LDS hash table: k_bin a power of two >= 3/2 n_points, k_binj
+                                  binj_hash_size() (any size) */
     int32_t max_mult;          /* kMaxMult: merge same-cell beams; 1: one entry per beam */
     int32_t lstride;
     int32_t pair_mode;         /* 1: entries are aligned row pairs (pair-row fine kernel); 2: joint

@@ -31,8 +31,9 @@ struct JointLaunch {
     int list_blocks = 0;
 };
 
-/* LDS bytes of k_binj for a frame of `tiles` endpoint tiles, n_points beams per slice and a
- * hash table of hash_size slots (a power of two >= 4/3 * 2 * n_points) */
+/* slots of k_binj's hash table for n_points beams per slice (>= 4/3 * 2 * n_points, any size) and the
+ * LDS bytes of k_binj for a frame of `tiles` endpoint tiles with that table */
+int binj_hash_size(int n_points);
 size_t binj_lds_bytes(int tiles, int n_points, int hash_size);
 
 /* grid = (ceil(max slices / 2), jobs); BinJob.sorted_pb / sorted_rc hold 2 * n_points entries

@@ -34,9 +34,24 @@
 namespace csm {
 
 /* ------------------------------------------------------------------ K0, joint */
+#ifdef CSM_BIN_TIMING
+/* tuning builds only (tools/bin_phases.py): cycles per phase of k_binj, one row of 16 counters per
+ * workgroup (thread 0, plain stores) behind BinJob.tuning_counters */
+#define BINJ_TICK(k)                                                                  \
+    do {                                                                              \
+        if (threadIdx.x == 0 && job.tuning_counters) {                                \
+            const unsigned long long now_ = __builtin_readcyclecounter();             \
+            reinterpret_cast<unsigned long long*>(job.tuning_counters)[dbg_row_ * 16 + (k)] += now_ - tick_; \
+            tick_ = now_;                                                             \
+        }                                                                             \
+    } while (0)
+#else
+#define BINJ_TICK(k) do { } while (0)
+#endif
+constexpr int kBinjNoBeam = 0x3fffffff;    /* row / column of the lanes behind the last beam */
 constexpr int kBinjBlock = 512;      /* threads per workgroup of the joint binning kernel: its hash table
-                                        (12 B per slot, 4096 slots for 2 x 1080 beams) allows two
-                                        workgroups per CU, so each brings 8 waves */
+                                        (12 B per slot, binj_hash_size(): 2880 slots for 2 x 1080 beams,
+                                        40 KB with the rest) lets four workgroups share a CU */
 
 /* One workgroup (kBinjBlock threads) per PAIR of theta slices (2p, 2p + 1; the last pair of
  * an odd number of slices holds one). Entry words:
@@ -49,7 +64,13 @@ constexpr int kBinjBlock = 512;      /* threads per workgroup of the joint binni
  * tiles + p * max_tiles, n_tiles[p]. The structure follows k_bin (csm_kernels.hip): an LDS
  * hash table keyed by (tile, row pair, column), runs of neighbouring lanes with one key
  * inserted once, the probes of kAhead iterations travelling together, a list of the slots
- * claimed (a wave appends its new slots behind one LDS counter). No classes: one count per tile. */
+ * claimed (a wave appends the new slots of its kAhead iterations behind one LDS counter with one
+ * atomic). No classes: one count per tile.
+ * The table has any size (slot = high word of hash x size), not a power of two: 4/3 of the beams
+ * instead of up to 8/3 is what brings four workgroups to a CU. Passes B and C walk the list with
+ * lanes 67 entries apart: the list is in beam order, so neighbouring entries belong to one tile and a
+ * wave walking it in order would send its 64 atomics per instruction to one LDS address (that, not
+ * the hash probes, was 90 % of the bank-conflict cycles of this kernel). */
 __device__ __forceinline__ void k_binj_body(const BinJob& job)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm_binj[];
@@ -77,39 +98,30 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
     /* slices t0 and t0 + 1 are contiguous in [n_theta][n_points]: beam i of the pair */
     const int32_t* col = job.hit_col + (size_t)t0 * n;
     const int32_t* row = job.hit_row + (size_t)t0 * n;
-    const uint32_t hmask = (uint32_t)hash_size - 1u;
-
-    constexpr int kAhead = 5;
-    constexpr int kBinBlock = kBinjBlock;      /* shadows the per-slice kernel's block size below */
-    int rv[kAhead], cv[kAhead];
-#pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-        const int i = u * kBinBlock + tid;
-        rv[u] = cv[u] = 0;
-        if (i < n2) {
-            rv[u] = row[i];
-            cv[u] = col[i];
-        }
+    const uint32_t hsize = (uint32_t)hash_size;
+#ifdef CSM_BIN_TIMING
+    unsigned long long tick_ = __builtin_readcyclecounter();
+    const size_t dbg_row_ = min((size_t)blockIdx.y * gridDim.x + blockIdx.x, (size_t)kBinDebugRows - 1);
+    if (threadIdx.x == 0 && job.tuning_counters) {
+        unsigned long long* row_ = reinterpret_cast<unsigned long long*>(job.tuning_counters) + dbg_row_ * 16;
+        for (int k = 0; k < 12; ++k)
+            row_[k] = 0ull;
+        row_[7] = 1ull;
     }
-    for (int i = tid; i < 2 * ntp; i += kBinBlock)
-        rowmask[i] = 0ull;
-    for (int i = tid; i < hash_size; i += kBinBlock) {
-        hval[i] = 0ull;
-        hkey[i] = 0u;
-    }
-    for (int i = tid; i < ntp; i += kBinBlock)
-        cnt[i] = 0u;
-    if (tid == 0)
-        list_n = 0u;
-    __syncthreads();
+#endif
 
-    const int r_max = uni(job.rows) - 1 - uni(job.y_lo);
-    const int c_max = uni(job.cols) - 1 - uni(job.x_lo);
+    /* (the job's fields first: their loads must not sit behind the barrier below, where waiting for them
+     * would wait for the beams too) */
     bool band = false;
+    int low_edge = 1;
     const int fs = uni(job.frame_shift);
     const int x_hi = uni(job.x_hi), y_hi = uni(job.y_hi), x_lo = uni(job.x_lo), y_lo = uni(job.y_lo);
+    /* inside the frame: 0 <= r + y_hi <= rows - 1 - y_lo + y_hi, the columns alike */
+    const uint32_t r_span = (uint32_t)(uni(job.rows) - 1 - y_lo + y_hi), c_span = (uint32_t)(uni(job.cols) - 1 - x_lo + x_hi);
+    const int lw = 6 + (tiles_x > 1 ? 32 - __builtin_clz(tiles_x - 1) : 0);    /* frame columns < 2^lw */
+    const unsigned long long from_me = ~0ull << lane, above_me = from_me << 1;
     const int n_band = uni(job.n_band);
-    const int n_iter = (n2 + kBinBlock - 1) / kBinBlock;
+    const int n_iter = (n2 + kBinjBlock - 1) / kBinjBlock;
     auto in_band = [&](int u, int w, int span, int known_lo) {
         if (u > 0 || u <= -span)
             return false;
@@ -117,11 +129,39 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
         return m != 0 && w - 1 - m >= known_lo;
     };
     const int known_r0 = uni(job.known_r0), known_c0 = uni(job.known_c0);
+
+    constexpr int kAhead = 5;
+    int rv[kAhead], cv[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+        const int i = u * kBinjBlock + tid;
+        rv[u] = cv[u] = kBinjNoBeam;
+        if (i < n2) {
+            rv[u] = row[i];
+            cv[u] = col[i];
+        }
+    }
+    {
+        /* masks, table and counts are contiguous: 16 bytes per lane and store (the last store may run
+         * into the list, which is written after the barrier) */
+        uint4* z = reinterpret_cast<uint4*>(sm_binj);
+        const int n16 = (20 * ntp + 12 * hash_size + 15) >> 4;
+        for (int i = tid; i < n16; i += kBinjBlock)
+            z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 0)
+        list_n = 0u;
+    /* the LDS stores only: the beams' global loads stay in flight across the barrier (__syncthreads()
+     * would wait for them too; the first use below waits) */
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    BINJ_TICK(0);
+
     for (int it0 = 0; it0 < n_iter; it0 += kAhead) {
         if (it0) {
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                const int i = (it0 + u) * kBinBlock + tid;
+                const int i = (it0 + u) * kBinjBlock + tid;
+                rv[u] = cv[u] = kBinjNoBeam;
                 if (i < n2) {
                     rv[u] = row[i];
                     cv[u] = col[i];
@@ -137,43 +177,33 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
             slot[u] = 0;
             beams[u] = 0ull;
             pend[u] = first[u] = false;
-            if (it0 + u >= n_iter)
-                continue;
-            const int i = (it0 + u) * kBinBlock + tid;
-            const int r = rv[u], c = cv[u];
-            const int rr = r + y_hi + fs, cc = c + x_hi;
-            const bool valid = i < n2 && rr >= fs && r <= r_max && cc >= 0 && c <= c_max;
+            /* (iterations behind the last beam run on kBinjNoBeam: no branch, the predicates stay in SGPRs) */
+            const int i = (it0 + u) * kBinjBlock + tid;
+            const int r = rv[u], c = cv[u];         /* kBinjNoBeam behind the last beam: invalid, far from the edge */
+            const uint32_t ry = (uint32_t)(r + y_hi), cx = (uint32_t)(c + x_hi);
+            const bool valid = ry <= r_span && cx <= c_span;
             const uint32_t sl = i >= n ? 1u : 0u;              /* which slice of the pair */
-            bool odd = false;
-            uint32_t cmp = 0xffffffffu;
-            if (valid) {
-                const uint32_t tile = ((uint32_t)rr / kTile) * (uint32_t)tiles_x + (uint32_t)cc / kTile;
-                const uint32_t rb = (uint32_t)rr % kTile, cb = (uint32_t)cc % kTile;
-                key[u] = ((tile << 12) | ((rb >> 1) << 6) | cb) + 1u;
-                odd = (rb & 1u) != 0;
-                cmp = key[u] | (sl << 31);                     /* a run never spans the two slices */
-            }
-            const uint32_t prev = (uint32_t)__shfl_up((int)cmp, 1, 64);
+            /* key: (pair row of the frame, column of the frame) + 1; the tile comes out of it again in
+             * passes B and C, where there is a quarter of the lanes to pay for it */
+            const uint32_t rr = ry + (uint32_t)fs;
+            key[u] = (((rr >> 1) << lw) | cx) + 1u;
+            const bool odd = valid && (rr & 1u) != 0;
+            const uint32_t cmp = valid ? key[u] | (sl << 31) : 0xffffffffu;   /* a run never spans the two slices */
+            /* the neighbour below: one DPP move (wave_shr:1; lane 0 is a head anyway) */
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~cmp, (int)cmp, 0x138, 0xf, 0xf, false);
             const bool head = valid && (lane == 0 || cmp != prev);
-            const unsigned long long hm = __ballot(head), vm = __ballot(valid), om = __ballot(odd);
-            const unsigned long long above = (hm | ~vm) & ~((2ull << lane) - 1ull);
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(head), vm = __builtin_amdgcn_ballot_w64(valid), om = __builtin_amdgcn_ballot_w64(odd);
+            const unsigned long long above = (hm | ~vm) & above_me;
             const int e = above ? __builtin_ctzll(above) : 64;
-            const unsigned long long run = (e == 64 ? ~0ull : (1ull << e) - 1ull) & ~((1ull << lane) - 1ull);
+            const unsigned long long run = (e == 64 ? ~0ull : (1ull << e) - 1ull) & from_me;
             const uint32_t co = (uint32_t)__popcll(run & om), ce = (uint32_t)__popcll(run) - co;
             beams[u] = (unsigned long long)(ce | (co << 16)) << (32u * sl);
-            slot[u] = (key[u] * 2654435761u) >> 12 & hmask;
+            /* multiplicative hash on the full-rate 24-bit multiplier: 18 bits of key x C, scaled to the table */
+            slot[u] = __umul24(__builtin_amdgcn_ubfe(__umul24(key[u], 0x3779b1u), 9, 18), hsize) >> 18;
             pend[u] = head;
-            const bool near_low_edge = i < n2 && (r + y_lo <= 0 || c + x_lo <= 0);
-            if (__any(near_low_edge)) {
-                if (near_low_edge)
-                    for (int b = 0; b < n_band; ++b) {
-                        const int w = job.band_win[b];
-                        if (in_band(r + y_lo, w, job.band_ny[b] * w, known_r0) ||
-                            in_band(c + x_lo, w, job.band_nx[b] * w, known_c0))
-                            band = true;
-                    }
-            }
+            low_edge = min(low_edge, min(r + y_lo, c + x_lo));
         }
+        BINJ_TICK(8);
         bool any = true;
         while (any) {
             uint32_t old[kAhead];
@@ -189,46 +219,89 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
                         atomicAdd(&hval[slot[u]], beams[u]);
                         pend[u] = false;
                     } else {
-                        slot[u] = (slot[u] + 1u) & hmask;
+                        slot[u] = slot[u] + 1u == hsize ? 0u : slot[u] + 1u;
                         any = true;
                     }
                 }
-            any = __any(any);
+            any = __builtin_amdgcn_ballot_w64(any) != 0ull;
         }
+        BINJ_TICK(9);
         /* the lanes that claimed an empty slot append it to the list */
+        {
+            unsigned long long fm[kAhead];
+            uint32_t claimed = 0;
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const unsigned long long fm = __ballot(first[u]);
-            if (fm) {                           /* wave-uniform */
+            for (int u = 0; u < kAhead; ++u) {
+                fm[u] = __builtin_amdgcn_ballot_w64(first[u]);
+                claimed += (uint32_t)__popcll(fm[u]);
+            }
+            if (claimed) {                      /* wave-uniform */
                 uint32_t base = 0;
                 if (lane == 0)
-                    base = atomicAdd(&list_n, (uint32_t)__popcll(fm));
+                    base = atomicAdd(&list_n, claimed);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (first[u])
-                    list[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint16_t)slot[u];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (first[u])
+                        list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm[u] >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)fm[u], 0u))] =
+                            (uint16_t)slot[u];
+                    base += (uint32_t)__popcll(fm[u]);
+                }
             }
+        }
+        BINJ_TICK(10);
+    }
+    /* Edge band (A8): only beams within a window of the map's low edge can be in it. One minimum per beam
+     * above; the modulo test reads the beams again, here, where little else is live (rare). */
+    if (__builtin_amdgcn_ballot_w64(low_edge <= 0) != 0ull) {
+        for (int i = tid; i < n2; i += kBinjBlock) {
+            const int r = row[i], c = col[i];
+            if (r + y_lo <= 0 || c + x_lo <= 0)
+                for (int b = 0; b < n_band; ++b) {
+                    const int w = job.band_win[b];
+                    if (in_band(r + y_lo, w, job.band_ny[b] * w, known_r0) ||
+                        in_band(c + x_lo, w, job.band_nx[b] * w, known_c0))
+                        band = true;
+                }
         }
     }
     if (band)
         atomicOr(job.flags, kFlagBandTouch);
     __syncthreads();
+    BINJ_TICK(1);
 
     const uint32_t max_mult = (uint32_t)uni(job.max_mult);
     auto chunks = [&](uint32_t b) { return (b + max_mult - 1u) / max_mult; };
     const int n_cells = uni((int)list_n);
     auto cell_slot = [&](int e) { return (uint32_t)list[e]; };
+    /* entries of a slot: its largest beam count in chunks of max_mult (15 for merged lists: a multiply) */
     auto entries_of = [&](unsigned long long hv) {
         const uint32_t lo = (uint32_t)hv, hi = (uint32_t)(hv >> 32);
-        return max(max(chunks(lo & 0xffffu), chunks(lo >> 16)), max(chunks(hi & 0xffffu), chunks(hi >> 16)));
+        const uint32_t m = max(max(lo & 0xffffu, lo >> 16), max(hi & 0xffffu, hi >> 16));
+        return max_mult == (uint32_t)kMaxMult ? __umul24(m + (uint32_t)kMaxMult - 1u, 0x8889u) >> 19 : chunks(m);
+    };
+    static_assert(kMaxMult == 15, "entries_of: (m + 14) * 0x8889 >> 19 is (m + 14) / 15 for m < 2^16");
+    /* the key of a slot -> tile, pair row in the tile, column in the tile */
+    auto decode = [&](uint32_t k1, int& tile, uint32_t& rk, uint32_t& cbk) {
+        const uint32_t cx = k1 & ((1u << lw) - 1u), rp = k1 >> lw;
+        tile = (int)((rp >> 5) * (uint32_t)tiles_x + (cx >> 6));
+        rk = rp & 31u;
+        cbk = cx & 63u;
     };
 
     /* Pass B: entries per tile, bounding boxes */
-    for (int e = tid; e < n_cells; e += kBinBlock) {
+    const int walk = (tid * 67) & (kBinjBlock - 1);       /* a permutation of the block's list positions */
+    for (int e0 = 0; e0 < n_cells; e0 += kBinjBlock) {
+        const int e = e0 + walk;
+        if (e >= n_cells)
+            continue;
         const uint32_t sl = cell_slot(e);
         const uint32_t k1 = hkey[sl] - 1u;
         const unsigned long long hv = hval[sl];
-        const int tile = (int)(k1 >> 12);
-        const uint32_t rk = (k1 >> 6) & 63u, cbk = k1 & 63u;
+        int tile;
+        uint32_t rk, cbk;
+        decode(k1, tile, rk, cbk);
         const bool any_even = (hv & 0x0000ffff0000ffffull) != 0, any_odd = (hv & 0xffff0000ffff0000ull) != 0;
         const uint32_t rlo = 2u * rk + (any_even ? 0u : 1u), rhi = 2u * rk + (any_odd ? 1u : 0u);
         atomicAdd(&cnt[tile], entries_of(hv));
@@ -236,44 +309,24 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
         atomicOr(&colmask[tile], 1ull << cbk);
     }
     __syncthreads();
+    BINJ_TICK(2);
 
-    /* exclusive scan of entry counts and of the records per tile */
-    const int chunk = (ntile + kBinBlock - 1) / kBinBlock;
-    const int lo = tid * chunk, hi = min(lo + chunk, ntile);
-    uint32_t csum = 0, ne = 0, excl_cnt, excl_rec;
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t c = cnt[i];
-        csum += c;
-        ne += (c + kJRec - 1) / kJRec;
-    }
-    {
-        uint32_t a = csum, b = ne;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
-            if (lane >= d) {
-                a += ua;
-                b += ub;
-            }
+    /* exclusive scan of entry counts and of the records per tile, then the records: the first wave
+     * alone (64 tiles for configs[1]: one per lane), the others wait at the barrier */
+    if (tid < 64) {
+        const int chunk = (ntile + 63) / 64;
+        const int lo = lane * chunk, hi = min(lo + chunk, ntile);
+        uint32_t csum = 0, ne = 0;
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t c = cnt[i];
+            csum += c;
+            ne += (c + kJRec - 1) / kJRec;
         }
-        __shared__ uint32_t wtot[2][kBinBlock / 64];
-        if (lane == 63) {
-            wtot[0][tid >> 6] = a;
-            wtot[1][tid >> 6] = b;
-        }
-        __syncthreads();
-        uint32_t ba = 0, bb2 = 0;
-        for (int w = 0; w < (tid >> 6); ++w) {
-            ba += wtot[0][w];
-            bb2 += wtot[1][w];
-        }
-        excl_cnt = ba + a - csum;
-        excl_rec = bb2 + b - ne;
-        if (tid == kBinBlock - 1)
-            job.n_tiles[p] = (int32_t)(bb2 + b);
-    }
-    {
-        uint32_t off = excl_cnt, slot_rec = excl_rec;
+        const uint32_t a = (uint32_t)wave_prefix_sum((int)csum), b = (uint32_t)wave_prefix_sum((int)ne);
+        if (lane == 63)
+            job.n_tiles[p] = (int32_t)b;
+        BINJ_TICK(3);
+        uint32_t off = a - csum, slot_rec = b - ne;
         TileRec* recs = job.tiles + (size_t)p * job.max_tiles;
         for (int i = lo; i < hi; ++i) {
             const uint32_t c = cnt[i];
@@ -300,19 +353,25 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
         }
     }
     __syncthreads();
+    BINJ_TICK(4);
 
     /* Pass C: the entries */
     uint32_t* out = job.sorted_pb + (size_t)p * 2 * n;
     uint32_t* out_rc = job.sorted_rc ? job.sorted_rc + (size_t)p * 2 * n : nullptr;
     const uint32_t lstride = (uint32_t)uni(job.lstride);
-    for (int e = tid; e < n_cells; e += kBinBlock) {
+    for (int e0 = 0; e0 < n_cells; e0 += kBinjBlock) {
+        const int e = e0 + walk;
+        if (e >= n_cells)
+            continue;
         const uint32_t sl = cell_slot(e);
         const uint32_t k1 = hkey[sl] - 1u;
         const unsigned long long hv = hval[sl];
-        const int tile = (int)(k1 >> 12);
+        int tile;
+        uint32_t rk, cbk;
+        decode(k1, tile, rk, cbk);
         const uint32_t rmin = (uint32_t)__builtin_ctzll(rowmask[tile]) & ~1u;
-        const uint32_t rb = (((k1 >> 6) & 63u) << 1) - rmin;        /* even */
-        const uint32_t cb = (k1 & 63u) - (uint32_t)__builtin_ctzll(colmask[tile]);
+        const uint32_t rb = (rk << 1) - rmin;        /* even */
+        const uint32_t cb = cbk - (uint32_t)__builtin_ctzll(colmask[tile]);
         uint32_t b0 = (uint32_t)hv & 0xffffu, b1 = ((uint32_t)hv >> 16), b2 = (uint32_t)(hv >> 32) & 0xffffu,
                  b3 = (uint32_t)(hv >> 48);
         const uint32_t total = entries_of(hv);
@@ -330,9 +389,10 @@ __device__ __forceinline__ void k_binj_body(const BinJob& job)
                 out_rc[pos] = mults | (rb << 7) | cb;
         }
     }
+    BINJ_TICK(5);
 }
 
-__global__ __launch_bounds__(kBinjBlock, 4) void k_binj_batch(const BinJob* jobs)
+__global__ __launch_bounds__(kBinjBlock, 8) void k_binj_batch(const BinJob* jobs)
 {
     k_binj_body(jobs[blockIdx.y]);
 }
@@ -1148,6 +1208,14 @@ hipError_t launch_joint(const csm::JointLaunch& L)
 } /* namespace */
 
 namespace csm {
+
+/* load factor <= 3/4 when every beam of the two slices lands on a cell of its own (in practice a quarter
+ * of that: 533 cells of 2160 beams for configs[1]); < 2^16 slots: the list holds 16-bit slot numbers */
+int binj_hash_size(int n_points)
+{
+    const int h = ((8 * n_points + 2) / 3 + 63) & ~63;
+    return h < 512 ? 512 : h;
+}
 
 size_t binj_lds_bytes(int tiles, int n_points, int hash_size)
 {

@@ -111,7 +111,7 @@ def test_bound_pass_off_is_identical(oracle):
 
 @pytest.mark.parametrize("n_beams,expect_bound_pass", [(1500, True), (2600, True), (6000, False)])
 def test_many_beams_joint_and_fallback(ctx, oracle, n_beams, expect_bound_pass):
-    """Above 1,365 beams the joint hash table of a slice pair takes a CU's LDS alone; above ~5,400
+    """Above ~2,200 beams the joint hash table of a slice pair takes a CU's LDS alone; above ~4,200
     the batch goes back to per-slice lists and the exact kernel on every block. Same records."""
     case = synth.csm_case(47, n_beams=n_beams, max_range=4.0)
     rx, ry, rt, Lr = 1.2, 1.2, math.radians(6), 4
