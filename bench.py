@@ -240,10 +240,10 @@ def loop_roofline(leaves, fine_ms, fine_n, entries_per_leaf_query=None, n_querie
     alg = 2.0 * N_BEAMS * leaves
     avg = fine_ms / max(1, fine_n) * 1e-3
     # HBM bytes per leaf launch: the committed PMC passes of the 256-query batch (one map per query)
-    traffic, traffic_src = pmc_traffic(os.path.join(ROOT, "profiles", "r02_loop_pmc_traffic.json"))
+    traffic, traffic_src = pmc_traffic(os.path.join(ROOT, "profiles", "r03_loop_pmc_traffic.json"))
     if traffic is not None and n_queries not in (None, 256):
         traffic, traffic_src = traffic * n_queries / 256.0, traffic_src + "; scaled to %d queries" % n_queries
-    d = {"bound": "lds", "kernel": "k_score_pairs_batch (leaf level, all queries of the batch in one launch)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
+    d = {"bound": "lds", "kernel": "leaf level of the batch, all queries in one launch chain: k_score_jointf_batch<124, 6> (packed-fp32 bound pass) + k_bound_select + k_score_joint_list<124, 6> in two rounds (exact pass)", "unit": "GB/s", "peak": LDS_PEAK_GBS,
          "avg_launch_us": avg * 1e6, "launches": fine_n, "traffic": traffic, "traffic_source": traffic_src,
          "hbm_frac_measured": traffic / avg / 1e9 / HBM_PEAK_GBS if traffic is not None and avg > 0 else None,
          "logical_hbm_gbs": alg / avg / 1e9 if avg > 0 else 0.0,
