@@ -491,7 +491,8 @@ def measure_config5(dev_index, runs=2, warmup=1):
     fine_us = kern.get("score_fine", 0.0)
     two_phase = info["two_phase"] == 1
     if two_phase and coarse_us >= fine_us:
-        dom, dom_us = "k_score_pairs on the phase-major box-max(4) copy (coarse pass: every coarse node)", coarse_us
+        dom, dom_us = ("k_score_joint_one (exact joint kernel over pairs of slices) on the phase-major box-max(4) copy "
+                       "(coarse pass: every coarse node)"), coarse_us
         lds = 4.0 * per_slice * info["coarse_nodes_scored"]
     else:
         dom, dom_us = "k_score_pairs%s (fine level)" % ("_list" if two_phase else ""), fine_us

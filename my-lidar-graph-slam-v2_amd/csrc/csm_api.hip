@@ -936,6 +936,112 @@ struct TwoPhaseCtl {
     uint32_t stats[4] = { 0, 0, 0, 0 };      /* mode 2, filled on request: items, kept, dropped */
 };
 
+/* Mode 1 on JOINT entries of slice pairs (csm_joint_kernels.hip: k_binj_one + k_score_joint_one), jobs
+ * by value. On the phase-major copy a tile holds the beams of one phase only (configs[4]: ~6 entries per
+ * staged window against ~53 at the fine level), so the pass is bound by staging; a pair of neighbouring
+ * slices shares every staged window. Returns kNotJoint where the joint tables do not fit (the caller
+ * then takes the per-slice pair kernel). */
+const int kNotJoint = -1000;
+
+int run_level_pass_joint(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
+                         const int32_t* hit_col_dev, const int32_t* hit_row_dev, uint32_t* flags, TwoPhaseCtl* tp)
+{
+    if (!ctx->tune.joint || !ctx->tune.two_slices || !p.fine.pairs || p.L != 1)
+        return kNotJoint;
+    PassPlan jp;
+    const int hash_size = csm::binj_hash_size(p.n);
+    const size_t binj_lds = csm::binj_lds_bytes(p.tiles_x * p.tiles_y, p.n, hash_size);
+    if (binj_lds > 150 * 1024 || !plan_pass_pairs(ctx->tune, p.nx, p.ny, &jp, true) || jp.lists != 2)
+        return kNotJoint;
+    jp.joint = true;
+    jp.weighted = true;
+    int rc;
+    const int n_pairs = (p.n_theta + 1) / 2;
+    const int max_tiles = std::min(2 * p.n, p.tiles_x * p.tiles_y) + 2 * p.n / kJRec + 1;
+    if ((rc = ensure(ctx, ctx->sorted, (size_t)n_pairs * 2 * p.n * 4 + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->tiles, (size_t)n_pairs * max_tiles * sizeof(TileRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->ntiles, (size_t)n_pairs * 8))) return rc;
+    BinJob bj;
+    std::memset(&bj, 0, sizeof(bj));
+    bj.hit_col = hit_col_dev;
+    bj.hit_row = hit_row_dev;
+    bj.sorted_pb = reinterpret_cast<uint32_t*>(ctx->sorted.p);
+    bj.tiles = reinterpret_cast<TileRec*>(ctx->tiles.p);
+    bj.n_tiles = reinterpret_cast<int32_t*>(ctx->ntiles.p);
+    bj.flags = flags;
+    bj.n_theta = p.n_theta;
+    bj.n_points = p.n;
+    bj.max_tiles = max_tiles;
+    bj.rows = g.rows;
+    bj.cols = g.cols;
+    bj.x_lo = p.x_lo;
+    bj.y_lo = p.y_lo;
+    bj.x_hi = p.x_hi;
+    bj.y_hi = p.y_hi;
+    bj.tiles_x = p.tiles_x;
+    bj.tiles_y = p.tiles_y;
+    bj.known_r0 = g.known_r0;
+    bj.known_c0 = g.known_c0;
+    bj.hash_size = hash_size;
+    bj.max_mult = kMaxMult;
+    bj.lstride = jp.lstride;
+    bj.pair_mode = 2;
+    bj.frame_shift = (p.ny - 1) & 1;
+    {
+        ScopedTimer tm(ctx, "bin");
+        if ((rc = launched_ok(ctx, csm::launch_binj_one(ctx->stream, ctx->device, bj, n_pairs, binj_lds), "joint binning")))
+            return rc;
+    }
+    ScoreJob fj;
+    std::memset(&fj, 0, sizeof(fj));
+    fj.rows = g.rows;
+    fj.cols = g.cols;
+    fj.pitch = g.pitch;
+    fj.sorted_pb = bj.sorted_pb;
+    fj.tiles = bj.tiles;
+    fj.n_tiles = bj.n_tiles;
+    fj.n_theta = p.n_theta;
+    fj.n_points = p.n;
+    fj.max_tiles = max_tiles;
+    fj.x_lo = p.x_lo;
+    fj.y_lo = p.y_lo;
+    fj.flags = flags;
+    fj.min_known = w->min_known;
+    fj.cells = g.levels[0].cells;
+    fj.xg = g.xg;
+    fj.xg_pitch = g.xg_pitch;
+    fj.xg_pad = g.xg_pad;
+    fj.nx = p.nx;
+    fj.ny = p.ny;
+    fj.stride = 1;
+    fj.rank_l = p.L;
+    fj.joint = 1;
+    /* every candidate's sums, stored; no arg-max, no record */
+    fj.acc_s = reinterpret_cast<uint32_t*>(ctx->coarse_s.p);
+    fj.acc_k = reinterpret_cast<uint32_t*>(ctx->coarse_k.p);
+    fj.acc_x_major = 2;
+    tp->level_s = fj.acc_s;
+    tp->level_k = fj.acc_k;
+    tp->nxs = p.nx;
+    tp->nys = p.ny;
+    const uint16_t* lane_map = nullptr;
+    if ((rc = lane_map_for(ctx, jp, &lane_map)))
+        return rc;
+    csm::JointLaunch L{};
+    L.stream = ctx->stream;
+    L.device = ctx->device;
+    L.grid = dim3(jp.ncb(), 1, 1);
+    L.lds_bytes = pass_lds_bytes(jp);
+    L.ls = jp.lstride;
+    L.R = jp.R;
+    L.cbx = jp.cbx;
+    L.groups = jp.groups;
+    L.lane_map = lane_map;
+    L.ncb = jp.ncb();
+    ScopedTimer tm(ctx, "score_coarse");
+    return launched_ok(ctx, csm::launch_joint_one(L, fj, n_pairs), "joint level pass");
+}
+
 int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
                const int32_t* hit_col_dev, const int32_t* hit_row_dev,
                csm_result* out_dev, const WindowOutputs* dumps, bool force_coarse = false,
@@ -1003,6 +1109,12 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         HIP_TRY(ctx, hipMemsetAsync(flags, 0, 4, ctx->stream));
     } else if (tp_mode != 1) {  /* the level pass sets no flag and has no finalize to clear one */
         ctx->flag_toggle++;
+    }
+
+    if (tp_mode == 1) {
+        const int rcj = run_level_pass_joint(ctx, g, w, p, hit_col_dev, hit_row_dev, flags, tp);
+        if (rcj != kNotJoint)
+            return rcj;
     }
 
     BinJob bj;
@@ -1097,6 +1209,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
             return rc;
     }
 
+    const BlockBest* tp_reduced = nullptr;
     ScoreJob fj = base;
     fj.cells = g.levels[0].cells;
     fj.xg = g.xg;
@@ -1148,10 +1261,11 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         if (p.fine.ncb() > 4096 || (size_t)p.n_theta * tp->nxs * tp->nys >= (1u << 26) || p.n > 4096)
             return fail(ctx, CSM_EINVAL, "internal: window too large for the two-phase work list");
         const size_t n_blocks = nt * ncb;
-        if ((rc = ensure(ctx, ctx->tp_items, 64 + n_blocks * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->tp_items, 64 + csm::kReducedBest * sizeof(BlockBest) + n_blocks * 4))) return rc;
         unsigned long long* best2 = reinterpret_cast<unsigned long long*>(ctx->tp_items.p);
         uint32_t* count = reinterpret_cast<uint32_t*>(best2 + 2);
-        uint32_t* items = count + 12;
+        BlockBest* reduced = reinterpret_cast<BlockBest*>(reinterpret_cast<char*>(ctx->tp_items.p) + 64);
+        uint32_t* items = reinterpret_cast<uint32_t*>(reduced + csm::kReducedBest);
         HIP_TRY(ctx, hipMemsetAsync(ctx->tp_items.p, 0, 64, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->best.p, 0, n_blocks * sizeof(BlockBest), ctx->stream));
         csm::TwoPhaseJob J;
@@ -1198,7 +1312,13 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
             if ((rc = launch_score_list(ctx, fj, p.fine, items, count, (int)std::min<size_t>(n_blocks, 2048))))
                 return rc;
         }
+        /* k_finalize reads kReducedBest records instead of one per block of the window */
+        if ((rc = launched_ok(ctx, csm::launch_reduce_items(ctx->stream, fj.block_best, items, count, (uint32_t)n_blocks,
+                                                            ncb, reduced), "record reduction")))
+            return rc;
+        tp_reduced = reduced;
         ctx->tp_count_dev = count;
+        ctx->tp_blocks_total = (int64_t)n_blocks;
     }
     if (tp_mode == 2) {
         /* launched above */
@@ -1237,6 +1357,10 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
     std::memset(&fin, 0, sizeof(fin));
     fin.block_best = fj.block_best;
     fin.n_entries = p.n_theta * ncb;
+    if (tp_reduced) {
+        fin.block_best = tp_reduced;
+        fin.n_entries = csm::kReducedBest;
+    }
     fin.nx = p.nx;
     fin.ny = p.ny;
     fin.rank_l = p.L;
@@ -3614,14 +3738,14 @@ int csm_last_search_info(csm_ctx* ctx, csm_search_info* out)
     out->coarse_nodes_scored = ctx->last_coarse_nodes;
     out->fine_candidates_scored = ctx->last_fine_candidates;
     if (ctx->tp_count_dev) {
-        uint32_t h[3] = { 0, 0, 0 };
+        uint32_t kept = 0;
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->tp_count_dev, 12, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&kept, ctx->tp_count_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         out->two_phase = 1;
-        out->blocks_scored = h[1];
-        out->blocks_skipped = h[2];
-        out->fine_candidates_scored = (int64_t)h[1] * ctx->last_block_candidates;
+        out->blocks_scored = kept;
+        out->blocks_skipped = ctx->tp_blocks_total - (int64_t)kept;
+        out->fine_candidates_scored = (int64_t)kept * ctx->last_block_candidates;
     }
     return CSM_OK;
 }

@@ -139,7 +139,8 @@ struct csm_ctx {
     void* q_pin = nullptr;           /* pinned: [ProjJob | angles | ranges] up, [record | uncertified count] back */
     size_t q_pin_cap = 0;
     DevBuf q_dev;
-    const uint32_t* tp_count_dev = nullptr;      /* [3] items / blocks kept / dropped of the last two-phase search */
+    const uint32_t* tp_count_dev = nullptr;      /* blocks kept (= items of the work list) by the last two-phase search */
+    int64_t tp_blocks_total = 0;                 /* ... of this many */
     int64_t last_coarse_nodes = 0, last_fine_candidates = 0, last_nominal = 0, last_block_candidates = 0;   /* csm_last_search_info */
     DevBuf fine_s, fine_k, tie, ex_fine, ex_fine_k, ex_coarse, ex_coarse_k, scan_dev, unc, sorted_rc, b_sorted_rc;
     std::map<std::array<int, 4>, uint16_t*> lane_maps;   /* lane_map_for(): (cbx, groups, R, LS) -> device table */

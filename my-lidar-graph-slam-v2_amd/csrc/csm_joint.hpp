@@ -43,6 +43,12 @@ int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, in
 
 int launch_joint_batch(const JointLaunch& launch);
 
+/* One window with its jobs by value (no job array in device memory): joint binning over n_pairs pairs of
+ * slices, then the exact joint kernel over launch.grid.x candidate blocks x n_pairs (launch.jobs_dev,
+ * grid.y / z, fp32 and the list fields are not used). The coarse pass of a coarse-first search. */
+int launch_binj_one(hipStream_t stream, int device, const BinJob& job, int n_pairs, size_t lds_bytes);
+int launch_joint_one(const JointLaunch& launch, const ScoreJob& job, int n_pairs);
+
 /* After the bound pass (approx_best of every job written): clears every job's BlockBest records and
  * lists the candidate blocks the exact kernel has to score: item = job << 18 | pair << 8 | block;
  * blocks >= split_cb go to items1 (the row block of the R = 6 launch). counts[2] must be zero.

@@ -397,6 +397,12 @@ __global__ __launch_bounds__(kBinjBlock, 8) void k_binj_batch(const BinJob* jobs
     k_binj_body(jobs[blockIdx.y]);
 }
 
+/* one window, its job by value (the coarse pass of a coarse-first search): grid = (pairs of slices) */
+__global__ __launch_bounds__(kBinjBlock, 8) void k_binj_one(BinJob job)
+{
+    k_binj_body(job);
+}
+
 /* ------------------------------------------------------------------ K1, joint */
 
 /* The multiply-adds of one entry: four blocks of R -- (even row, slice 0), (even row, slice 1),
@@ -1036,6 +1042,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_score_joint_batch(const ScoreJob*
     score_body_joint<LS, R>(jobs[bz], cbx, groups, lane_map, bx, by, bb);
 }
 
+/* One window, its job by value: grid.x = pairs of slices x candidate blocks, the pairs fastest
+ * (neighbouring workgroups stage the same neighbourhood of the map: L2 hits, as k_score_pairs'
+ * slice-major order). The coarse pass of a coarse-first search (csm_phase_kernels.hip) runs on it:
+ * on the phase-major copy a tile holds the few beams of ONE phase, staging dominates, and a pair of
+ * slices shares every staged window. */
+template <int LS, int R>
+__global__ __launch_bounds__(kBlock, 4) void k_score_joint_one(ScoreJob job, int cbx, int groups,
+                                                               const uint16_t* lane_map, int n_pairs, BlockBase bb)
+{
+    const int by = (int)(blockIdx.x % (uint32_t)n_pairs), bx = (int)(blockIdx.x / (uint32_t)n_pairs);
+    score_body_joint<LS, R>(job, cbx, groups, lane_map, bx, by, bb);
+}
+
 /* ---- after the bound pass: which candidate blocks the exact kernel still has to score ----
  * One workgroup per job (window). M = the window's greatest fp32 key. A block (pair of slices,
  * candidate block) whose own greatest key lies below M by more than the two passes' rounding
@@ -1205,6 +1224,18 @@ hipError_t launch_joint(const csm::JointLaunch& L)
     return hipGetLastError();
 }
 
+template <int LS, int R>
+hipError_t launch_joint_one_t(const csm::JointLaunch& L, const csm::ScoreJob& job, int n_pairs)
+{
+    auto kernel = csm::k_score_joint_one<LS, R>;
+    const hipError_t e = grant_lds(L.device, reinterpret_cast<const void*>(kernel), L.lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n_pairs * L.grid.x), dim3(csm::kBlock), L.lds_bytes, L.stream, job, L.cbx,
+                       L.groups, L.lane_map, n_pairs, csm::BlockBase{ L.row_base, L.cb_base, L.ncb });
+    return hipGetLastError();
+}
+
 } /* namespace */
 
 namespace csm {
@@ -1233,11 +1264,25 @@ int launch_binj_batch(hipStream_t stream, int device, const BinJob* jobs_dev, in
     return (int)hipGetLastError();
 }
 
+int launch_binj_one(hipStream_t stream, int device, const BinJob& job, int n_pairs, size_t lds_bytes)
+{
+    const hipError_t e = grant_lds(device, reinterpret_cast<const void*>(k_binj_one), lds_bytes);
+    if (e != hipSuccess)
+        return (int)e;
+    hipLaunchKernelGGL(k_binj_one, dim3(n_pairs, 1), dim3(kBinjBlock), lds_bytes, stream, job);
+    return (int)hipGetLastError();
+}
+
 #define JOINT_CASE(LS)                                                                 \
     if (L.ls == LS && L.R == 8)                                                        \
         return (int)launch_joint<LS, 8>(L);                                            \
     if (L.ls == LS && L.R == 6)                                                        \
         return (int)launch_joint<LS, 6>(L);
+#define JOINT_ONE_CASE(LS)                                                             \
+    if (L.ls == LS && L.R == 8)                                                        \
+        return (int)launch_joint_one_t<LS, 8>(L, job, n_pairs);                        \
+    if (L.ls == LS && L.R == 6)                                                        \
+        return (int)launch_joint_one_t<LS, 6>(L, job, n_pairs);
 
 int launch_expand_pairs_f(hipStream_t stream, const uint16_t* cells, int rows, int cols, int pitch, float* xgf,
                           int xg_prows, int xg_pitch, int pad)
@@ -1266,6 +1311,17 @@ int launch_joint_batch(const JointLaunch& L)
     JOINT_CASE(156) JOINT_CASE(162) JOINT_CASE(182)
 #endif
     return -1;      /* no instantiation for this row pitch */
+}
+
+int launch_joint_one(const JointLaunch& L, const ScoreJob& job, int n_pairs)
+{
+#ifdef CSM_FAST_BUILD
+    JOINT_ONE_CASE(150) JOINT_ONE_CASE(156)
+#else
+    JOINT_ONE_CASE(86) JOINT_ONE_CASE(98) JOINT_ONE_CASE(118) JOINT_ONE_CASE(124) JOINT_ONE_CASE(130) JOINT_ONE_CASE(150)
+    JOINT_ONE_CASE(156) JOINT_ONE_CASE(162) JOINT_ONE_CASE(182)
+#endif
+    return -1;
 }
 
 } /* namespace csm */

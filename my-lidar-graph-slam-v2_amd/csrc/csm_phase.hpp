@@ -39,7 +39,7 @@ struct TwoPhaseJob {
     /* outputs */
     unsigned long long* best;    /* [2]: packed best eligible coarse node; best fine key under it */
     uint32_t* items;             /* work list of the fine launch: slice << 12 | block */
-    uint32_t* count;             /* [4]: items, blocks kept, blocks dropped, - */
+    uint32_t* count;             /* [1]: items = blocks kept */
     uint32_t cap;
 };
 
@@ -49,6 +49,10 @@ int launch_coarse_best(hipStream_t stream, const TwoPhaseJob& job);
 int launch_fine_under_best(hipStream_t stream, const TwoPhaseJob& job);
 /* the fine blocks holding an eligible coarse node whose key reaches best[1] -> items / count */
 int launch_mark_blocks(hipStream_t stream, const TwoPhaseJob& job);
+/* the BlockBest records of the listed blocks (block_best[slice * ncb + block]) reduced to kReducedBest records */
+constexpr int kReducedBest = 64;
+int launch_reduce_items(hipStream_t stream, const BlockBest* block_best, const uint32_t* items, const uint32_t* count,
+                        uint32_t cap, int ncb, BlockBest* out);
 
 } /* namespace csm */
 #endif

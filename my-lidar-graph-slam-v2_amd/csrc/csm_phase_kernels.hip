@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "csm_phase.hpp"
+#include "csm_score_common.hpp"
 
 namespace csm {
 
@@ -149,46 +150,82 @@ __global__ __launch_bounds__(256) void k_fine_under_best(TwoPhaseJob job)
     }
 }
 
-/* one thread per (slice, fine candidate block) */
+/* one wave per (slice, fine candidate block): the lanes read the coarse nodes under the block (the y
+ * index fastest: consecutive words) and vote; lane 0 appends the block to the work list. count[0] =
+ * blocks kept (the host derives the dropped ones). */
 __global__ __launch_bounds__(256) void k_mark_blocks(TwoPhaseJob job)
 {
     const int total = job.n_theta * job.ncb;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool keep = false;
-    if (i < total) {
-        const int t = i / job.ncb, cb = i - t * job.ncb;
-        const bool all = (*job.flags & kFlagBandTouch) != 0;
-        const unsigned long long F = job.best[1];
-        if (all) {
-            keep = true;
-        } else if (F > 0) {
-            const int bx = cb % job.ncbx, by = cb / job.ncbx;
-            const int x0 = bx * job.cbx, x1 = min(job.nx, x0 + job.cbx) - 1;
-            const int y0 = by * job.cby, y1 = min(job.ny, y0 + job.cby) - 1;
-            if (x1 >= x0 && y1 >= y0)
-                for (int xc = x0 / job.L; xc <= x1 / job.L && !keep; ++xc)
-                    for (int yc = y0 / job.L; yc <= y1 / job.L; ++yc) {
-                        const size_t ni = ((size_t)t * job.nxs + xc) * job.nys + yc;
-                        const uint32_t k = job.coarse_k[ni];
-                        if ((int)k < job.min_known || k == 0)
-                            continue;
-                        if (32268ull * k + 499ull * (unsigned long long)job.coarse_s[ni] >= F) {
-                            keep = true;
-                            break;
-                        }
-                    }
-        }
-        if (keep) {
-            const uint32_t pos = atomicAdd(job.count, 1u);
-            if (pos < job.cap)
-                job.items[pos] = ((uint32_t)t << 12) | (uint32_t)cb;
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (i >= total)
+        return;
+    const int t = i / job.ncb, cb = i - t * job.ncb;
+    bool keep = (*job.flags & kFlagBandTouch) != 0;
+    const unsigned long long F = job.best[1];
+    if (!keep && F > 0) {
+        const int bx = cb % job.ncbx, by = cb / job.ncbx;
+        const int x0 = bx * job.cbx, x1 = min(job.nx, x0 + job.cbx) - 1;
+        const int y0 = by * job.cby, y1 = min(job.ny, y0 + job.cby) - 1;
+        if (x1 >= x0 && y1 >= y0) {
+            const int xr0 = x0 / job.L, yr0 = y0 / job.L;
+            const int nyr = y1 / job.L - yr0 + 1, nodes = (x1 / job.L - xr0 + 1) * nyr;
+            bool mine = false;
+            for (int j = lane; j < nodes; j += 64) {
+                const int xc = xr0 + j / nyr, yc = yr0 + j % nyr;
+                const size_t ni = ((size_t)t * job.nxs + xc) * job.nys + yc;
+                const uint32_t k = job.coarse_k[ni];
+                if ((int)k >= job.min_known && k != 0 &&
+                    32268ull * k + 499ull * (unsigned long long)job.coarse_s[ni] >= F)
+                    mine = true;
+            }
+            keep = __builtin_amdgcn_ballot_w64(mine) != 0ull;
         }
     }
-    /* statistics: blocks kept / dropped, one atomic per wave */
-    const unsigned long long km = __ballot(keep), am = __ballot(i < total);
+    if (keep && lane == 0) {
+        const uint32_t pos = atomicAdd(job.count, 1u);
+        if (pos < job.cap)
+            job.items[pos] = ((uint32_t)t << 12) | (uint32_t)cb;
+    }
+}
+
+/* The BlockBest records of the work list's blocks reduced to kReducedBest records (k_finalize then reads
+ * those instead of one record per block of the window: 262k for configs[4], a single workgroup's loop). */
+__global__ __launch_bounds__(256) void k_reduce_items(const BlockBest* __restrict__ bb, const uint32_t* __restrict__ items,
+                                                     const uint32_t* __restrict__ count, uint32_t cap, int ncb,
+                                                     BlockBest* __restrict__ out)
+{
+    __shared__ unsigned long long red_key[4], red_rank[4];
+    __shared__ uint32_t red_cnt[4];
+    const uint32_t n = min(*count, cap);
+    unsigned long long key = 0, rank = ~0ull;
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t it = items[i];
+        const BlockBest b = bb[(size_t)(it >> 12) * ncb + (it & 4095u)];
+        best_combine(key, rank, cnt, b.key, b.rank, b.count);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long k2 = shfl_xor_u64(key, m), r2 = shfl_xor_u64(rank, m);
+        const uint32_t c2 = __shfl_xor(cnt, m, 64);
+        best_combine(key, rank, cnt, k2, r2, c2);
+    }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(job.count + 1, (uint32_t)__popcll(km));
-        atomicAdd(job.count + 2, (uint32_t)(__popcll(am) - __popcll(km)));
+        red_key[threadIdx.x >> 6] = key;
+        red_rank[threadIdx.x >> 6] = rank;
+        red_cnt[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            best_combine(key, rank, cnt, red_key[w], red_rank[w], red_cnt[w]);
+        BlockBest r;
+        r.key = key;
+        r.rank = rank;
+        r.count = cnt;
+        r.pad = 0;
+        out[blockIdx.x] = r;
     }
 }
 
@@ -229,7 +266,14 @@ int launch_fine_under_best(hipStream_t stream, const TwoPhaseJob& job)
 int launch_mark_blocks(hipStream_t stream, const TwoPhaseJob& job)
 {
     const int total = job.n_theta * job.ncb;
-    hipLaunchKernelGGL(k_mark_blocks, dim3((total + 255) / 256), dim3(256), 0, stream, job);
+    hipLaunchKernelGGL(k_mark_blocks, dim3((total + 3) / 4), dim3(256), 0, stream, job);
+    return (int)hipGetLastError();
+}
+
+int launch_reduce_items(hipStream_t stream, const BlockBest* block_best, const uint32_t* items, const uint32_t* count,
+                        uint32_t cap, int ncb, BlockBest* out)
+{
+    hipLaunchKernelGGL(k_reduce_items, dim3(kReducedBest), dim3(256), 0, stream, block_best, items, count, cap, ncb, out);
     return (int)hipGetLastError();
 }
 

@@ -56,7 +56,7 @@ for name, pick, wpl in (("csm", "_batch<", int(os.environ.get("CSM_BENCH_WINDOWS
                         ("loop", "_batch<", 256)):
     per = counters(name)
     if name == "cfg5":      # the coarse-first search: the pair kernel on the phase-major copy + the fine work list
-        dom = [k for k in per if "k_score_pairs<" in k or "k_score_pairs_list<" in k]
+        dom = [k for k in per if "k_score_pairs<" in k or "k_score_pairs_list<" in k or "k_score_joint_one<" in k]
     else:                   # the joint kernels of a batch: fp32 bound pass (if any) + exact kernel
         dom = [k for k in per if "k_score_joint" in k]
     doc = {"library_version": version, "windows_per_launch": wpl, "per_kernel": per,
