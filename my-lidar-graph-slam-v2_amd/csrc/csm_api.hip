@@ -1261,12 +1261,14 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         if (p.fine.ncb() > 4096 || (size_t)p.n_theta * tp->nxs * tp->nys >= (1u << 26) || p.n > 4096)
             return fail(ctx, CSM_EINVAL, "internal: window too large for the two-phase work list");
         const size_t n_blocks = nt * ncb;
-        if ((rc = ensure(ctx, ctx->tp_items, 64 + csm::kReducedBest * sizeof(BlockBest) + n_blocks * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->tp_items, 64 + csm::kReducedBest * sizeof(BlockBest) + n_blocks * 5))) return rc;
         unsigned long long* best2 = reinterpret_cast<unsigned long long*>(ctx->tp_items.p);
         uint32_t* count = reinterpret_cast<uint32_t*>(best2 + 2);
         BlockBest* reduced = reinterpret_cast<BlockBest*>(reinterpret_cast<char*>(ctx->tp_items.p) + 64);
         uint32_t* items = reinterpret_cast<uint32_t*>(reduced + csm::kReducedBest);
+        unsigned char* keep = reinterpret_cast<unsigned char*>(items + n_blocks);
         HIP_TRY(ctx, hipMemsetAsync(ctx->tp_items.p, 0, 64, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(keep, 0, n_blocks, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->best.p, 0, n_blocks * sizeof(BlockBest), ctx->stream));
         csm::TwoPhaseJob J;
         std::memset(&J, 0, sizeof(J));
@@ -1298,6 +1300,7 @@ int run_window(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const Plan& p,
         J.best = best2;
         J.items = items;
         J.count = count;
+        J.keep = keep;
         J.cap = (uint32_t)n_blocks;
         {
             ScopedTimer tm(ctx, "select");

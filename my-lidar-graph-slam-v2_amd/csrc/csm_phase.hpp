@@ -40,6 +40,7 @@ struct TwoPhaseJob {
     unsigned long long* best;    /* [2]: packed best eligible coarse node; best fine key under it */
     uint32_t* items;             /* work list of the fine launch: slice << 12 | block */
     uint32_t* count;             /* [1]: items = blocks kept */
+    unsigned char* keep;         /* [n_theta * ncb] scratch of the marking, zero on entry */
     uint32_t cap;
 };
 
@@ -47,7 +48,7 @@ struct TwoPhaseJob {
 int launch_coarse_best(hipStream_t stream, const TwoPhaseJob& job);
 /* best[1] = greatest fine key among the L x L candidates under that node (exact integer sums) */
 int launch_fine_under_best(hipStream_t stream, const TwoPhaseJob& job);
-/* the fine blocks holding an eligible coarse node whose key reaches best[1] -> items / count */
+/* the fine blocks holding an eligible coarse node whose key reaches best[1] -> items / count (job.keep zeroed) */
 int launch_mark_blocks(hipStream_t stream, const TwoPhaseJob& job);
 /* the BlockBest records of the listed blocks (block_best[slice * ncb + block]) reduced to kReducedBest records */
 constexpr int kReducedBest = 64;

@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void k_coarse_best(TwoPhaseJob job)
     }
 }
 
-/* one workgroup: the L x L fine candidates under the best coarse node, exact integer keys */
-__global__ __launch_bounds__(256) void k_fine_under_best(TwoPhaseJob job)
+/* one workgroup of 16 waves: the L x L fine candidates under the best coarse node, exact integer keys */
+__global__ __launch_bounds__(1024) void k_fine_under_best(TwoPhaseJob job)
 {
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long red[16];
     const unsigned long long packed = job.best[0];
     unsigned long long fbest = 0;
     if (packed) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_fine_under_best(TwoPhaseJob job)
         const int L = job.L;
         /* a wave per fine candidate, lanes over beams */
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int f = wave; f < L * L; f += 4) {
+        for (int f = wave; f < L * L; f += 16) {
             const int x = job.x_lo + xc * L + f / L, y = job.y_lo + yc * L + f % L;
             unsigned long long s = 0;
             uint32_t k = 0;
@@ -144,46 +144,59 @@ __global__ __launch_bounds__(256) void k_fine_under_best(TwoPhaseJob job)
         red[threadIdx.x >> 6] = fbest;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 16; ++w)
             fbest = fbest > red[w] ? fbest : red[w];
         job.best[1] = fbest;
     }
 }
 
-/* one wave per (slice, fine candidate block): the lanes read the coarse nodes under the block (the y
- * index fastest: consecutive words) and vote; lane 0 appends the block to the work list. count[0] =
- * blocks kept (the host derives the dropped ones). */
-__global__ __launch_bounds__(256) void k_mark_blocks(TwoPhaseJob job)
+/* The fine blocks that can still win, in two steps. k_mark_nodes: one thread per coarse node in memory
+ * order (466 MB of sums for configs[4], read once and coalesced; one wave per block reading its 21 x 12
+ * nodes in 48-byte runs took 0.33 ms); a node that is eligible with key >= F sets the flag byte of every
+ * fine block one of its L x L candidates lies in. k_compact_blocks: the flagged blocks (all of them when a
+ * beam can reach the edge band) become the work list, one atomic per wave. */
+__global__ __launch_bounds__(256) void k_mark_nodes(TwoPhaseJob job)
+{
+    const unsigned long long F = job.best[1];
+    if (F == 0 || (*job.flags & kFlagBandTouch) != 0)
+        return;
+    const size_t per_t = (size_t)job.nxs * job.nys;
+    const size_t total = per_t * job.n_theta;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t k = job.coarse_k[i];
+        if ((int)k < job.min_known || k == 0)
+            continue;
+        if (32268ull * k + 499ull * (unsigned long long)job.coarse_s[i] < F)
+            continue;
+        const int t = (int)(i / per_t);
+        const int xc = (int)((i % per_t) / job.nys), yc = (int)(i % job.nys);
+        if (xc >= job.nxc || yc >= job.nyc)
+            continue;
+        const int bx0 = (xc * job.L) / job.cbx, bx1 = min(job.nx - 1, xc * job.L + job.L - 1) / job.cbx;
+        const int by0 = (yc * job.L) / job.cby, by1 = min(job.ny - 1, yc * job.L + job.L - 1) / job.cby;
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx)
+                job.keep[(size_t)t * job.ncb + by * job.ncbx + bx] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_blocks(TwoPhaseJob job)
 {
     const int total = job.n_theta * job.ncb;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (i >= total)
+    const bool all = (*job.flags & kFlagBandTouch) != 0;
+    const bool keep = i < total && (all || job.keep[i] != 0);
+    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+    if (!km)
         return;
-    const int t = i / job.ncb, cb = i - t * job.ncb;
-    bool keep = (*job.flags & kFlagBandTouch) != 0;
-    const unsigned long long F = job.best[1];
-    if (!keep && F > 0) {
-        const int bx = cb % job.ncbx, by = cb / job.ncbx;
-        const int x0 = bx * job.cbx, x1 = min(job.nx, x0 + job.cbx) - 1;
-        const int y0 = by * job.cby, y1 = min(job.ny, y0 + job.cby) - 1;
-        if (x1 >= x0 && y1 >= y0) {
-            const int xr0 = x0 / job.L, yr0 = y0 / job.L;
-            const int nyr = y1 / job.L - yr0 + 1, nodes = (x1 / job.L - xr0 + 1) * nyr;
-            bool mine = false;
-            for (int j = lane; j < nodes; j += 64) {
-                const int xc = xr0 + j / nyr, yc = yr0 + j % nyr;
-                const size_t ni = ((size_t)t * job.nxs + xc) * job.nys + yc;
-                const uint32_t k = job.coarse_k[ni];
-                if ((int)k >= job.min_known && k != 0 &&
-                    32268ull * k + 499ull * (unsigned long long)job.coarse_s[ni] >= F)
-                    mine = true;
-            }
-            keep = __builtin_amdgcn_ballot_w64(mine) != 0ull;
-        }
-    }
-    if (keep && lane == 0) {
-        const uint32_t pos = atomicAdd(job.count, 1u);
+    uint32_t base = 0;
+    if (lane == 0)
+        base = atomicAdd(job.count, (uint32_t)__popcll(km));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (keep) {
+        const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+        const int t = i / job.ncb, cb = i - t * job.ncb;
         if (pos < job.cap)
             job.items[pos] = ((uint32_t)t << 12) | (uint32_t)cb;
     }
@@ -259,14 +272,17 @@ int launch_coarse_best(hipStream_t stream, const TwoPhaseJob& job)
 
 int launch_fine_under_best(hipStream_t stream, const TwoPhaseJob& job)
 {
-    hipLaunchKernelGGL(k_fine_under_best, dim3(1), dim3(256), 0, stream, job);
+    hipLaunchKernelGGL(k_fine_under_best, dim3(1), dim3(1024), 0, stream, job);
     return (int)hipGetLastError();
 }
 
 int launch_mark_blocks(hipStream_t stream, const TwoPhaseJob& job)
 {
     const int total = job.n_theta * job.ncb;
-    hipLaunchKernelGGL(k_mark_blocks, dim3((total + 3) / 4), dim3(256), 0, stream, job);
+    const size_t nodes = (size_t)job.n_theta * job.nxs * job.nys;
+    const int blocks = (int)(nodes + 255 < (size_t)4096 * 256 ? (nodes + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_mark_nodes, dim3(blocks), dim3(256), 0, stream, job);
+    hipLaunchKernelGGL(k_compact_blocks, dim3((total + 255) / 256), dim3(256), 0, stream, job);
     return (int)hipGetLastError();
 }
 
