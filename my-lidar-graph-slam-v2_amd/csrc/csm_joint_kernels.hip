@@ -788,6 +788,15 @@ __device__ __forceinline__ void joint_fmads(uint32_t w, const unsigned long long
 #undef CSM_JFMA_E
 #undef CSM_JFMA_O
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
 /* ftab_addr: LDS byte address of the record's float table (16 B per entry: beams of even / odd
  * row of slice 0, of slice 1); the two broadcast reads of an entry ride in the same lgkmcnt queue
  * as its R/2 + 1 slot reads. */
@@ -813,10 +822,6 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
         lds_read_b64<16 * K>(faddr, f[0]);
         lds_read_b64<16 * K + 8>(faddr, f[1]);
     };
-    using k0 = std::integral_constant<int, 0>;
-    using k1 = std::integral_constant<int, 1>;
-    using k2 = std::integral_constant<int, 2>;
-    using k3 = std::integral_constant<int, 3>;
     /* waits until all but the `LATER` youngest LDS reads have landed; ties every register the
      * mads are about to read */
     auto wait = [&](auto later, unsigned long long (&q)[NQ], unsigned long long (&f)[2]) {
@@ -830,35 +835,45 @@ __device__ __forceinline__ void joint_gather_f(uint32_t lane_addr, uint32_t ftab
     using now_t = std::integral_constant<int, 0>;
     uint32_t pb_cur = lpb[lane];
     int j = 0;
+    /* N entries through the pipeline: two entries in flight from the first wait to the last; the reads drain
+     * once per pass (the first wait of a pass sees the full LDS latency: 8 entries per pass instead of 4
+     * took 2.2 % off the launch; 16 per pass gave half of that back, its code no longer sits well in the
+     * instruction cache, and carrying two entries in flight from one pass into the next makes the register
+     * sets loop-carried: 128 VGPRs and scratch). Register sets a, b, c, d in turn; entry u's float-table row is an immediate
+     * offset from the pass's first row. */
+    auto pass = [&](auto n_) {
+        constexpr int N = decltype(n_)::value;
+        uint32_t o[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+            o[u] = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + u) & 63);
+        const uint32_t fbase = ftab_addr + (uint32_t)j * 16u;
+        unsigned long long q[4][NQ], f[4][2];
+        issue(o[0], fbase, std::integral_constant<int, 0>(), q[0], f[0]);
+        if constexpr (N > 1)
+            issue(o[1], fbase, std::integral_constant<int, 1>(), q[1], f[1]);
+        static_for<0, N>([&](auto u_) {
+            constexpr int U = decltype(u_)::value;
+            if constexpr (U + 1 < N)
+                wait(later_t(), q[U % 4], f[U % 4]);
+            else
+                wait(now_t(), q[U % 4], f[U % 4]);
+            joint_fmads<R>(o[U], q[U % 4], f[U % 4][0], f[U % 4][1], ea, oa, eb, ob);
+            if constexpr (U + 2 < N)
+                issue(o[U + 2], fbase, std::integral_constant<int, U + 2>(), q[(U + 2) % 4], f[(U + 2) % 4]);
+        });
+        j += N;
+    };
     while (j < cnt) {
         const int stop = min(cnt, (j | 63) + 1);
-        for (; j + 4 <= stop; j += 4) {
-            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
-            const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 1) & 63);
-            const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 2) & 63);
-            const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, (j + 3) & 63);
-            const uint32_t fbase = ftab_addr + (uint32_t)j * 16u;
-            unsigned long long qa[NQ], qb[NQ], qc[NQ], qd[NQ], fa[2], fb[2], fc[2], fd[2];
-            issue(o0, fbase, k0(), qa, fa);
-            issue(o1, fbase, k1(), qb, fb);
-            wait(later_t(), qa, fa);
-            joint_fmads<R>(o0, qa, fa[0], fa[1], ea, oa, eb, ob);
-            issue(o2, fbase, k2(), qc, fc);
-            wait(later_t(), qb, fb);
-            joint_fmads<R>(o1, qb, fb[0], fb[1], ea, oa, eb, ob);
-            issue(o3, fbase, k3(), qd, fd);
-            wait(later_t(), qc, fc);
-            joint_fmads<R>(o2, qc, fc[0], fc[1], ea, oa, eb, ob);
-            wait(now_t(), qd, fd);
-            joint_fmads<R>(o3, qd, fd[0], fd[1], ea, oa, eb, ob);
-        }
-        for (; j < stop; ++j) {
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pb_cur, j & 63);
-            unsigned long long qa[NQ], fa[2];
-            issue(o, ftab_addr + (uint32_t)j * 16u, k0(), qa, fa);
-            wait(now_t(), qa, fa);
-            joint_fmads<R>(o, qa, fa[0], fa[1], ea, oa, eb, ob);
-        }
+#ifndef CSM_ABL_GROUP4
+        while (j + 8 <= stop)
+            pass(std::integral_constant<int, 8>());
+#endif
+        while (j + 4 <= stop)
+            pass(std::integral_constant<int, 4>());
+        while (j < stop)
+            pass(std::integral_constant<int, 1>());
         if ((j & 63) == 0 && j < cnt)
             pb_cur = lpb[j + lane];
     }
