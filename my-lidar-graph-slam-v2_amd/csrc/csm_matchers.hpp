@@ -23,6 +23,7 @@ struct PassPlan {
     int lists = 1;            /* entry lists in LDS: 2 = the batch kernel that takes two slices per workgroup */
     bool joint = false;       /* ... on joint entries of the two slices (one list; csm_joint_kernels.hip) */
     bool fp32 = false;        /* this launch is the packed-fp32 bound pass of the joint kernel */
+    int list_lds = -1;        /* LDS bytes of the entry lists if not lists * kPbMax words (plan_pass_pairs) */
     int ncb() const { return ncbx * ncby; }
 };
 
@@ -100,7 +101,7 @@ size_t bin_lds_bytes(int tiles, int n_points);
 int ilog2_exact(int v);
 bool plan_pass(const Tuning& tune, int nx, int ny, int stride, PassPlan* out);
 size_t pair_lds_bytes(int ls, int cby, int lists);
-bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two_slices = false);
+bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two_slices = false, int list_lds = -1);
 int xgrid_pad_for(int nx, int ny);
 int pick_buffers(const Tuning& tune, size_t lds_one, long blocks);
 size_t pass_lds_bytes(const PassPlan& p);

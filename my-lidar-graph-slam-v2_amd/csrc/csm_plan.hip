@@ -211,11 +211,16 @@ size_t pair_lds_bytes(int ls, int cby, int lists)
 
 /* two_slices: plan for the batch kernel that takes two theta slices per workgroup
  * (a second entry list in LDS) */
-bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two_slices)
+bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two_slices, int list_lds)
 {
     const int lists = two_slices ? 2 : 1;
     if (!tune.two_slices && two_slices)
         return plan_pass_pairs(tune, nx, ny, out, false);
+    /* LDS of a launch: the window copy + its entry lists (kPbMax words per list of the pair kernels; list_lds
+     * bytes where the caller knows better: the joint kernels keep kJRec words) */
+    auto lds_of = [&](int ls, int cby) {
+        return list_lds >= 0 ? pair_lds_bytes(ls, cby, 0) + (size_t)list_lds : pair_lds_bytes(ls, cby, lists);
+    };
     double best = -1.0;
     const int max_cbx = kPairLS[sizeof(kPairLS) / sizeof(kPairLS[0]) - 1] - 65;
     /* R = candidate rows per lane: 8, or 6 where that covers the rows with fewer
@@ -232,6 +237,7 @@ bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two
         p.log2s = 0;
         p.pairs = true;
         p.lists = lists;
+        p.list_lds = list_lds;
         p.R = R;
         p.ncbx = ncbx;
         p.cbx = ceil_div(nx, ncbx);
@@ -267,11 +273,11 @@ bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two
         /* two workgroups per CU: at most 80 KB of LDS each INCLUDING the kernel's static
          * __shared__ arrays (a plan at exactly 80 KB of dynamic LDS ran one workgroup per
          * CU: configs[4] took 87 ms instead of 56) */
-        while (g > 1 && pair_lds_bytes(p.lstride, g * R, lists) > 80 * 1024 - 1024)
+        while (g > 1 && lds_of(p.lstride, g * R) > 80 * 1024 - 1024)
             --g;
         if (force_g && force_g <= g)
             g = force_g;
-        if (g < 1 || pair_lds_bytes(p.lstride, g * R, lists) > 160 * 1024 - 256)
+        if (g < 1 || lds_of(p.lstride, g * R) > 160 * 1024 - 256)
             continue;
         p.ncby = ceil_div(ny, g * R);
         if (!force_g)
@@ -284,7 +290,7 @@ bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two
                             (0.01 * ((kTile + g * R) / 2 + 1) * p.lstride + 46.0 * (R + 6) + 450.0);
         if (tune.plan_debug)
             fprintf(stderr, "[plan %dx%d] R %d ncbx %d cbx %d LS %d groups %d ncby %d lds %zu cost %.0f\n", nx, ny, R,
-                    ncbx, p.cbx, p.lstride, g, p.ncby, pair_lds_bytes(p.lstride, g * R, lists), cost);
+                    ncbx, p.cbx, p.lstride, g, p.ncby, lds_of(p.lstride, g * R), cost);
         if (best < 0 || cost < best) {
             best = cost;
             *out = p;
@@ -297,7 +303,7 @@ bool plan_pass_pairs(const Tuning& tune, int nx, int ny, PassPlan* out, bool two
         for (int ls : kPairLS)
             have = have || ls == tune.pair_ls;
         if (have && tune.pair_ls >= out->cbx + 65 &&
-            pair_lds_bytes(tune.pair_ls, out->groups * out->R, lists) <= 160 * 1024 - 256)
+            lds_of(tune.pair_ls, out->groups * out->R) <= 160 * 1024 - 256)
             out->lstride = tune.pair_ls;
     }
     return true;
@@ -324,7 +330,8 @@ int pick_buffers(const Tuning& tune, size_t lds_one, long blocks)
 size_t pass_lds_bytes(const PassPlan& p)
 {
     if (p.pairs)
-        return pair_lds_bytes(p.lstride, p.groups * p.R, p.lists);
+        return p.list_lds >= 0 ? pair_lds_bytes(p.lstride, p.groups * p.R, 0) + (size_t)p.list_lds
+                               : pair_lds_bytes(p.lstride, p.groups * p.R, p.lists);
     const int cby = p.groups * p.R;
     const int rows = p.stride > 1 ? ((kTile + p.stride - 1) / p.stride + cby - 1) * p.stride
                                   : kTile + cby - 1;

@@ -22,7 +22,8 @@ int run_level_pass_joint(csm_ctx* ctx, DeviceGrid& g, const csm_window* w, const
     PassPlan jp;
     const int hash_size = csm::binj_hash_size(p.n);
     const size_t binj_lds = csm::binj_lds_bytes(p.tiles_x * p.tiles_y, p.n, hash_size);
-    if (binj_lds > 150 * 1024 || !plan_pass_pairs(ctx->tune, p.nx, p.ny, &jp, true) || jp.lists != 2)
+    /* the exact joint kernel keeps kJRec entry words next to the window copy (not two kPbMax lists) */
+    if (binj_lds > 150 * 1024 || !plan_pass_pairs(ctx->tune, p.nx, p.ny, &jp, true, kJRec * 4) || jp.lists != 2)
         return kNotJoint;
     jp.joint = true;
     jp.weighted = true;
