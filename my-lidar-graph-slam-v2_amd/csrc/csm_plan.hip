@@ -64,18 +64,43 @@ void search_step_from_max(double resolution, double max_range, double* step_x, d
 /* scan_finite_max of every query; returns the first offending query or -1 */
 int scans_finite_max(const csm_loop_query* queries, int n_queries, double* max_range)
 {
+    /* A loop detection matches ONE scan against many submaps: a query whose scan shares its arrays and its
+     * sensor pose with the query before it reuses that query's result (256 x 1080 doubles walked once
+     * instead of 256 times, and no worker threads: 0.1 ms of a 1.85 ms batch). */
+    auto same_scan = [&](int a, int b) {
+        const csm_scan& x = queries[a].scan;
+        const csm_scan& y = queries[b].scan;
+        return x.angles == y.angles && x.ranges == y.ranges && x.n_points == y.n_points &&
+               std::memcmp(x.relative_sensor_pose, y.relative_sensor_pose, sizeof(x.relative_sensor_pose)) == 0;
+    };
+    int distinct = 1;
+    for (int i = 1; i < n_queries; ++i)
+        distinct += same_scan(i, i - 1) ? 0 : 1;
     std::atomic<int> bad(n_queries);
-    host_parallel_for(n_queries, 128, [&](int lo, int hi) {
+    auto range = [&](int lo, int hi) {
+        bool prev_ok = false;
         for (int i = lo; i < hi; ++i) {
             const csm_scan& sc = queries[i].scan;
-            if (!sc.angles || !sc.ranges || sc.n_points < 1 || !scan_finite_max(&sc, &max_range[i])) {
+            bool ok;
+            if (i > lo && same_scan(i, i - 1)) {
+                ok = prev_ok;
+                max_range[i] = max_range[i - 1];
+            } else {
+                ok = sc.angles && sc.ranges && sc.n_points >= 1 && scan_finite_max(&sc, &max_range[i]);
+            }
+            prev_ok = ok;
+            if (!ok) {
                 int cur = bad.load();
                 while (i < cur && !bad.compare_exchange_weak(cur, i)) {
                 }
                 return;
             }
         }
-    });
+    };
+    if (distinct * 8 <= n_queries)
+        range(0, n_queries);
+    else
+        host_parallel_for(n_queries, 128, range);
     return bad.load() < n_queries ? bad.load() : -1;
 }
 
